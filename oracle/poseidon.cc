@@ -1,0 +1,115 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see poseidon.h).
+#include "poseidon.h"
+#include <mutex>
+
+namespace orc {
+
+// ---- rand_chacha 0.3.1 (Cargo.lock:644-647) ChaCha8Rng::seed_from_u64(0) + rand 0.8 gen_range(0..p),
+// the recipe recorded in SURVEY.md App. A.2.
+namespace {
+struct ChaCha8 {
+  uint32_t key[8]; uint64_t counter = 0; uint32_t buf[16]; int pos = 16;
+  static inline uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+  static inline void qr(uint32_t* s, int a, int b, int c, int d) {
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = rotl(s[d], 16);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = rotl(s[b], 12);
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = rotl(s[d], 8);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = rotl(s[b], 7);
+  }
+  void seed_from_u64(uint64_t state) {
+    // rand_core's default seed_from_u64: PCG32 stream fills the 32-byte seed.
+    const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
+    for (int i = 0; i < 8; i++) {
+      state = state * MUL + INC;
+      uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+      uint32_t rot = (uint32_t)(state >> 59);
+      key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+  }
+  void block() {
+    uint32_t in[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
+    for (int i = 0; i < 8; i++) in[4 + i] = key[i];
+    in[12] = (uint32_t)counter; in[13] = (uint32_t)(counter >> 32); in[14] = 0; in[15] = 0;
+    uint32_t s[16]; memcpy(s, in, sizeof s);
+    for (int r = 0; r < 4; r++) {
+      qr(s, 0, 4, 8, 12); qr(s, 1, 5, 9, 13); qr(s, 2, 6, 10, 14); qr(s, 3, 7, 11, 15);
+      qr(s, 0, 5, 10, 15); qr(s, 1, 6, 11, 12); qr(s, 2, 7, 8, 13); qr(s, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) buf[i] = s[i] + in[i];
+    counter++; pos = 0;
+  }
+  uint32_t next_u32() { if (pos >= 16) block(); return buf[pos++]; }
+  uint64_t next_u64() { uint64_t lo = next_u32(); uint64_t hi = next_u32(); return lo | (hi << 32); }
+  uint64_t gen_range_p() {  // rand 0.8 UniformInt::sample_single for 0..p (widening multiply + zone reject)
+    const uint64_t zone = P - 1;  // (p << lz(p)) - 1 with lz = 0
+    for (;;) { u128 m = (u128)next_u64() * P; if ((u64)m <= zone) return (u64)(m >> 64); }
+  }
+};
+u64 RC[360];
+std::once_flag rc_once;
+}
+
+const u64* poseidon_round_constants() {
+  std::call_once(rc_once, [] {
+    ChaCha8 rng; rng.seed_from_u64(0);
+    for (int i = 0; i < 360; i++) RC[i] = rng.gen_range_p();
+  });
+  return RC;
+}
+
+// Same round function as the generic template (add constants -> S-box -> MDS), with the MDS row accumulated
+// in 128 bits and reduced once (the constants are < 2^6, so 12 products fit easily).
+void poseidon_permute(u64 st[12]) {
+  const u64* rc = poseidon_round_constants();
+  for (int r = 0; r < N_ROUNDS; r++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * r + i]);
+    bool full = r < N_FULL_HALF || r >= N_FULL_HALF + N_PARTIAL;
+    if (full) for (int i = 0; i < 12; i++) st[i] = sbox7(FB(st[i])).v;
+    else st[0] = sbox7(FB(st[0])).v;
+    u64 out[12];
+    for (int k = 0; k < 12; k++) {
+      u128 acc = (u128)st[k] * MDS_DIAG[k];
+      for (int i = 0; i < 12; i++) acc += (u128)st[(i + k) % 12] * MDS_CIRC[i];
+      out[k] = gl_red128(acc);
+    }
+    memcpy(st, out, sizeof out);
+  }
+}
+
+// Literal (slow) form through the field-generic template; tests compare it with poseidon_permute.
+void poseidon_permute_generic(u64 st[12]) {
+  const u64* rc = poseidon_round_constants();
+  FB s[12];
+  for (int i = 0; i < 12; i++) s[i] = FB(st[i]);
+  for (int r = 0; r < N_ROUNDS; r++) {
+    for (int i = 0; i < 12; i++) s[i] = s[i] + FB(rc[12 * r + i]);
+    bool full = r < N_FULL_HALF || r >= N_FULL_HALF + N_PARTIAL;
+    if (full) for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+    else s[0] = sbox7(s[0]);
+    mds_layer_t(s);
+  }
+  for (int i = 0; i < 12; i++) st[i] = s[i].v;
+}
+
+Hash hash_no_pad(const u64* x, size_t len) {
+  u64 st[12] = {0};
+  for (size_t off = 0; off < len; off += SPONGE_RATE) {
+    size_t m = len - off < (size_t)SPONGE_RATE ? len - off : SPONGE_RATE;
+    for (size_t i = 0; i < m; i++) st[i] = x[off + i];   // overwrite mode
+    poseidon_permute(st);
+  }
+  return Hash{st[0], st[1], st[2], st[3]};
+}
+
+Hash hash_or_noop(const u64* x, size_t len) {
+  if (len <= 4) { Hash h{0, 0, 0, 0}; for (size_t i = 0; i < len; i++) h[i] = x[i]; return h; }
+  return hash_no_pad(x, len);
+}
+
+Hash two_to_one(const Hash& l, const Hash& r) {
+  u64 st[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+  poseidon_permute(st);
+  return Hash{st[0], st[1], st[2], st[3]};
+}
+
+} // namespace orc
