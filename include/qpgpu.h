@@ -1,0 +1,104 @@
+/* qpgpu — C ABI of the MI355X (gfx950) Plonky2 prover backend for the Quantus wormhole / voting circuits.
+ *
+ * This is the drop-in seam for the reference's hot path: the body of
+ *   ProverCircuitData::prove(PartialWitness)  (qp-plonky2 1.1.1, reached from
+ *   WormholeProver::prove  — /root/reference/wormhole/prover/src/lib.rs:233-237 — and from
+ *   aggregate_chunk's circuit_data.prove(pw) — wormhole/aggregator/src/circuits/tree.rs:136)
+ * after witness generation: `prove_with_partition_witness` (stages 1-10 of SURVEY.md §3.3).
+ * A `gpu` feature in a qp-plonky2 fork binds these symbols with bindgen; the wrappers
+ * in the reference repo need no source change.
+ *
+ * Conventions: all integers little-endian; field elements are canonical Goldilocks u64 (< 2^64-2^32+1);
+ * matrices are column-major ([column][row], one polynomial per contiguous run of n values, natural row order).
+ * Every function returns 0 on success or a negative qpgpu_status; the text is in qpgpu_last_error()
+ * (thread-local). Nothing throws or aborts across this boundary.
+ */
+#ifndef QPGPU_H
+#define QPGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qpgpu_status {
+  QPGPU_OK = 0,
+  QPGPU_ERR_ARG = -1,        /* bad argument / unsupported circuit shape or gate */
+  QPGPU_ERR_NO_DEVICE = -2,  /* no gfx950 device / HIP runtime failure at init */
+  QPGPU_ERR_HIP = -3,        /* a HIP call failed */
+  QPGPU_ERR_OOM = -4,
+  QPGPU_ERR_BUFFER = -5,     /* output buffer too small */
+  QPGPU_ERR_ZETA = -6,       /* zeta^n == 1 (upstream's "opening point is in the subgroup" exit) */
+  QPGPU_ERR_POW = -7,        /* supplied pow_witness invalid, or grinding found nothing */
+  QPGPU_ERR_WITNESS = -8     /* non-canonical field element in an input */
+} qpgpu_status;
+
+/* Gate tags = qp-plonky2's default gate-serializer ids as they appear in CommonCircuitData
+ * (wormhole/bench-data/common.bin). */
+enum { QPGPU_GATE_ARITHMETIC = 0, QPGPU_GATE_BASESUM2 = 2, QPGPU_GATE_CONSTANT = 3, QPGPU_GATE_NOOP = 9,
+       QPGPU_GATE_POSEIDON = 11, QPGPU_GATE_PUBLIC_INPUT = 12 };
+
+typedef struct qpgpu_gate { uint32_t tag; uint32_t pad; uint64_t param; } qpgpu_gate;
+
+/* CommonCircuitData + ProverOnlyCircuitData content the device path needs (what the reference loads with
+ * WormholeProver::new_from_bytes — wormhole/prover/src/lib.rs:105-137). */
+typedef struct qpgpu_circuit_desc {
+  uint32_t degree_bits, num_wires, num_routed, num_constants;      /* num_constants counts selector columns too */
+  uint32_t num_challenges, quotient_degree_factor, num_partial_products, num_public_inputs;
+  uint32_t num_gate_constraints, zero_knowledge;
+  uint32_t fri_rate_bits, fri_cap_height, fri_num_queries, fri_pow_bits;
+  uint32_t fri_num_layers; uint32_t fri_arity_bits[8];
+  uint32_t num_gates, num_selector_groups;
+  const qpgpu_gate* gates;                 /* [num_gates] */
+  const uint32_t* selector_indices;        /* [num_gates] */
+  const uint32_t* selector_group_ranges;   /* [num_selector_groups][2] = (lo, hi) */
+  const uint64_t* k_is;                    /* [num_routed] */
+  const uint64_t* constants_sigmas;        /* [num_constants + num_routed][n], values on the trace subgroup */
+  uint64_t circuit_digest[4];
+} qpgpu_circuit_desc;
+
+typedef struct qpgpu_ctx qpgpu_ctx;
+typedef struct qpgpu_circuit qpgpu_circuit;
+
+typedef struct qpgpu_prove_opts {
+  const uint64_t* salts;      /* zk only: [3 oracles][4][N] leaf-order salt columns (prover-side randomness is an input,
+                                 SURVEY.md App. A.10); NULL => derive from salt_seed on the device */
+  uint64_t salt_seed;
+  uint64_t pow_witness;       /* used when have_pow_witness != 0; otherwise the smallest valid witness is ground */
+  uint32_t have_pow_witness;
+  uint32_t wires_on_device;   /* wires pointer(s) are device pointers (already resident in HBM) */
+  void* stream;               /* hipStream_t to enqueue on, or NULL for the context's own stream */
+} qpgpu_prove_opts;
+
+const char* qpgpu_last_error(void);
+int qpgpu_device_count(void);
+
+int qpgpu_ctx_create(int device, qpgpu_ctx** out);
+void qpgpu_ctx_destroy(qpgpu_ctx* ctx);
+
+/* Uploads the preprocessed columns, computes the constants/sigmas LDE + Merkle tree once and keeps it resident
+ * (the work `builder.build_prover()` does at wormhole/circuit/src/circuit.rs:102-104). The handle is immutable and
+ * may be shared by threads. */
+int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_circuit** out);
+void qpgpu_circuit_destroy(qpgpu_circuit* c);
+/* constants_sigmas Merkle cap (2^cap_height digests x 4 u64) — the VerifierOnlyCircuitData content. */
+int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit* c, uint64_t* out_cap);
+/* Exact size of ProofWithPublicInputs::to_bytes() for this circuit. */
+size_t qpgpu_proof_size(const qpgpu_circuit* c);
+
+/* prove_with_partition_witness: full witness matrix -> ProofWithPublicInputs::to_bytes().
+ * wires: [num_wires][n] column-major. Re-entrant: each call uses its own stream + workspace. */
+int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
+                const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* `batch` independent proofs of the same circuit, stream-pipelined on one GPU (BASELINE config #3; the unit the
+ * aggregator shards per GPU, wormhole/aggregator/src/circuits/tree.rs:92-103). wires[i], public_inputs[i],
+ * out + i*out_stride. opts->salt_seed / salts apply per proof as salt_seed + i / salts + i*3*4*N. */
+int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wires, const uint64_t* const* public_inputs,
+                      size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride,
+                      size_t* out_lens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

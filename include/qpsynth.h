@@ -1,0 +1,41 @@
+/* qpsynth — synthetic "wormhole-shaped" / "voting-shaped" circuit + witness generator (host only, no GPU).
+ *
+ * Stands in for the two host-side pieces of the reference that need the Rust toolchain (absent here):
+ * the CircuitBuilder output of WormholeCircuit::new (/root/reference/wormhole/circuit/src/circuit.rs:76-108)
+ * and qp-plonky2's generate_partial_witness behind WormholeProver::commit (wormhole/prover/src/lib.rs:209-225).
+ * Gate mix follows SURVEY.md §8(d) (from wormhole/circuit/src/storage_proof/mod.rs:169-243, nullifier.rs:230-238,
+ * unspendable_account.rs:194-204). It is an input generator for tests and bench.py, not part of the drop-in ABI.
+ */
+#ifndef QPSYNTH_H
+#define QPSYNTH_H
+#include "qpgpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qpsynth_params {
+  uint32_t degree_bits;
+  uint32_t zero_knowledge;                 /* 1: standard_recursion_zk_config shape (salts + random Noop rows) */
+  uint32_t n_poseidon, n_basesum, n_arith, n_constant;
+  uint32_t n_copies;                       /* number of copy constraints (non-identity sigma entries) */
+  uint32_t fri_num_layers; uint32_t fri_arity_bits[8];
+  uint64_t circuit_seed;
+} qpsynth_params;
+
+typedef struct qpsynth_circuit qpsynth_circuit;
+
+/* Presets: "A" leaf non-zk k=13, "B" leaf zk k=14, "V" voting-shaped k=20, "T" tiny k=6 test circuit. */
+int qpsynth_preset(const char* name, qpsynth_params* out);
+int qpsynth_circuit_create(const qpsynth_params* p, qpsynth_circuit** out);
+void qpsynth_circuit_destroy(qpsynth_circuit* c);
+const qpgpu_circuit_desc* qpsynth_circuit_desc(const qpsynth_circuit* c);
+/* Full witness for proof index `seed`: wires [num_wires][n] column-major, public_inputs [16]. */
+int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, uint64_t* public_inputs);
+/* Salt columns exactly as the device derives them from opts.salt_seed: out [3][4][N]. */
+void qpsynth_salts(const qpsynth_circuit* c, uint64_t salt_seed, uint64_t* out);
+const char* qpsynth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -80,4 +80,80 @@ int orc_transcript_pins(const uint8_t* common_b, size_t common_len, const uint8_
   } catch (std::exception& e) { return fail(e.what()); }
 }
 
+
+// ---- circuit handle: CommonCircuitData fields + constants/sigmas values (the "circuit package")
+void* orc_circuit_create(int degree_bits, int num_wires, int num_routed, int num_constants, int num_challenges, int qdf,
+                         int num_partial_products, int num_public_inputs, int num_gate_constraints, int zk,
+                         int rate_bits, int cap_height, int num_queries, int pow_bits, int n_layers, const uint32_t* arity_bits,
+                         int n_gates, const uint32_t* gate_tags, const u64* gate_params, const uint32_t* selector_indices,
+                         int n_groups, const uint32_t* group_ranges, const u64* k_is, const u64* constants_sigmas,
+                         const u64* digest, int threads) {
+  try {
+    auto* oc = new OrcCircuit(); Common& c = oc->common;
+    c.num_wires = num_wires; c.num_routed = num_routed; c.cfg_num_constants = 2; c.security_bits = 100; c.num_challenges = num_challenges;
+    c.max_qdf = qdf; c.use_base_arith = true; c.zk = zk; c.rate_bits = rate_bits; c.cap_height = cap_height; c.num_queries = num_queries;
+    c.pow_bits = pow_bits; for (int i = 0; i < n_layers; i++) c.arity_bits.push_back((int)arity_bits[i]);
+    c.degree_bits = degree_bits; c.hiding = zk;
+    for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(Gate{(int)gate_tags[i], gate_params[i]}); }
+    for (int i = 0; i < n_groups; i++) c.groups.push_back({(int)group_ranges[2 * i], (int)group_ranges[2 * i + 1]});
+    c.qdf = qdf; c.num_gate_constraints = num_gate_constraints; c.num_constants = num_constants; c.num_public_inputs = num_public_inputs;
+    c.k_is.assign(k_is, k_is + num_routed); c.num_partial_products = num_partial_products;
+    memcpy(oc->digest.data(), digest, 32);
+    size_t n = c.n(); oc->constants_sigmas.assign(constants_sigmas, constants_sigmas + (size_t)c.num_preprocessed() * n);
+    oc->pre = preprocess(c, oc->constants_sigmas.data(), threads);
+    return oc;
+  } catch (std::exception& e) { fail(e.what()); return nullptr; }
+}
+void orc_circuit_destroy(void* h) { delete (OrcCircuit*)h; }
+void orc_circuit_cap(void* h, u64* out) { auto* oc = (OrcCircuit*)h; size_t k = 0; for (auto& hh : oc->pre.tree.cap()) { memcpy(out + 4 * k, hh.data(), 32); k++; } }
+
+long orc_prove(void* h, const u64* wires, const u64* public_inputs, const u64* salts, int have_pow, u64 pow_witness, int threads,
+               uint8_t* out, size_t cap) {
+  try {
+    auto* oc = (OrcCircuit*)h;
+    ProverInputs in{&oc->common, oc->digest, oc->constants_sigmas.data(), wires, public_inputs, salts, have_pow != 0, pow_witness, threads};
+    std::string err; Proof p = prove(in, oc->pre, &err);
+    if (!err.empty()) return fail(err);
+    auto b = serialize_proof(p);
+    if (b.size() > cap) return fail("output buffer too small");
+    memcpy(out, b.data(), b.size()); return (long)b.size();
+  } catch (std::exception& e) { return fail(e.what()); }
+}
+int orc_verify(void* h, const uint8_t* proof_b, size_t proof_len) {
+  try {
+    auto* oc = (OrcCircuit*)h;
+    Proof p = parse_proof(proof_b, proof_len, oc->common);
+    VerifierOnly v; v.cap_height = oc->common.cap_height; v.constants_sigmas_cap = oc->pre.tree.cap(); v.circuit_digest = oc->digest;
+    std::string r = verify(p, oc->common, v);
+    if (!r.empty()) return fail(r);
+    return 0;
+  } catch (std::exception& e) { return fail(e.what()); }
+}
+// Witness sanity: every gate constraint vanishes on every trace row, and the permutation argument closes
+// (grand product over all routed cells is 1 for random beta/gamma). Returns 0 if consistent; else -1 with a message.
+int orc_check_witness(void* h, const u64* wires, const u64* public_inputs) {
+  auto* oc = (OrcCircuit*)h; const Common& c = oc->common; size_t n = c.n();
+  Hash pih = hash_no_pad(public_inputs, c.num_public_inputs);
+  FB pi[4] = {FB(pih[0]), FB(pih[1]), FB(pih[2]), FB(pih[3])};
+  std::vector<FB> consts(c.num_constants), w(c.num_wires), out(c.num_gate_constraints);
+  for (size_t i = 0; i < n; i++) {
+    for (int k = 0; k < c.num_constants; k++) consts[k] = FB(oc->constants_sigmas[(size_t)k * n + i]);
+    for (int k = 0; k < c.num_wires; k++) w[k] = FB(wires[(size_t)k * n + i]);
+    eval_gate_constraints<FB>(c, consts.data(), w.data(), pi, out.data());
+    for (int k = 0; k < c.num_gate_constraints; k++) if (out[k].v != 0) return fail("gate constraint " + std::to_string(k) + " nonzero at row " + std::to_string(i));
+  }
+  u64 beta = 0x123456789abcdefULL, gamma = 0xfedcba987654321ULL, num = 1, den = 1, wn = gl_root(c.degree_bits), x = 1;
+  for (size_t i = 0; i < n; i++) {
+    for (int j = 0; j < c.num_routed; j++) {
+      u64 wv = wires[(size_t)j * n + i];
+      num = gl_mul(num, gl_add(gl_add(wv, gl_mul(beta, gl_mul(c.k_is[j], x))), gamma));
+      den = gl_mul(den, gl_add(gl_add(wv, gl_mul(beta, oc->constants_sigmas[(size_t)(c.num_constants + j) * n + i])), gamma));
+    }
+    x = gl_mul(x, wn);
+  }
+  if (num != den) return fail("copy constraints violated (grand product != 1)");
+  return 0;
+}
+int orc_max_threads() { return omp_get_max_threads(); }
+
 } // extern "C"
