@@ -184,3 +184,131 @@ class OracleCircuit:
             oracle().orc_circuit_destroy(self.h)
         except Exception:
             pass
+
+
+_qpgpu = None
+def qpgpu():
+    """libqpgpu.so — the product: HIP kernels + C-ABI (include/qpgpu.h). Fails loudly if it is not built."""
+    global _qpgpu
+    if _qpgpu is None:
+        so = os.path.join(PKG, "libqpgpu.so")
+        if not os.path.exists(so):
+            raise RuntimeError("libqpgpu.so missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(so)
+        L.qpgpu_last_error.restype = ctypes.c_char_p
+        L.qpgpu_test_permute.argtypes = [u64p, ctypes.c_size_t]
+        L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.qpgpu_test_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
+        L.qpgpu_test_merkle.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_bitrev.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
+        L.qpgpu_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_ctx_destroy.argtypes = [ctypes.c_void_p]
+        L.qpgpu_circuit_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(CircuitDesc), ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_circuit_destroy.argtypes = [ctypes.c_void_p]
+        L.qpgpu_circuit_constants_sigmas_cap.argtypes = [ctypes.c_void_p, u64p]
+        L.qpgpu_proof_size.restype = ctypes.c_size_t
+        L.qpgpu_proof_size.argtypes = [ctypes.c_void_p]
+        L.qpgpu_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.POINTER(ProveOpts),
+                                  ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_prove_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64p),
+                                        ctypes.c_size_t, ctypes.POINTER(ProveOpts), ctypes.c_char_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        _qpgpu = L
+    return _qpgpu
+
+
+class GpuCircuit:
+    """qpgpu_ctx + qpgpu_circuit: the product's resident circuit handle (include/qpgpu.h)."""
+
+    def __init__(self, desc, device=0):
+        L = qpgpu()
+        self.desc = desc
+        self.ctx = ctypes.c_void_p()
+        gpu_check(L.qpgpu_ctx_create(device, ctypes.byref(self.ctx)))
+        self.h = ctypes.c_void_p()
+        gpu_check(L.qpgpu_circuit_create(self.ctx, ctypes.byref(desc), ctypes.byref(self.h)))
+        self.proof_size = L.qpgpu_proof_size(self.h)
+
+    def cap(self):
+        out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
+        gpu_check(qpgpu().qpgpu_circuit_constants_sigmas_cap(self.h, ptr(out)))
+        return out
+
+    def prove(self, wires, pis, salts=None, salt_seed=0, pow_witness=None, wires_dev_ptr=None, stream=None):
+        L = qpgpu()
+        o = ProveOpts()
+        o.salts = ptr(salts) if salts is not None else None
+        o.salt_seed = salt_seed
+        o.have_pow_witness = 0 if pow_witness is None else 1
+        o.pow_witness = 0 if pow_witness is None else pow_witness
+        o.wires_on_device = 0 if wires_dev_ptr is None else 1
+        o.stream = stream
+        if wires_dev_ptr is None:
+            wires = np.ascontiguousarray(wires, dtype=np.uint64)
+            wp = wires.ctypes.data
+        else:
+            wp = wires_dev_ptr
+        buf = ctypes.create_string_buffer(self.proof_size)
+        n = ctypes.c_size_t()
+        gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
+        return buf.raw[:n.value]
+
+    def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False):
+        L = qpgpu()
+        b = len(pis_list)
+        o = ProveOpts()
+        o.salt_seed = salt_seed
+        o.wires_on_device = 1 if wires_on_device else 0
+        if wires_on_device:
+            wp = (ctypes.c_void_p * b)(*wires_list)
+        else:
+            wires_list = [np.ascontiguousarray(w, dtype=np.uint64) for w in wires_list]
+            wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in wires_list])
+        pp = (u64p * b)(*[ptr(p) for p in pis_list])
+        buf = ctypes.create_string_buffer(self.proof_size * b)
+        lens = (ctypes.c_size_t * b)()
+        gpu_check(L.qpgpu_prove_batch(self.h, b, wp, pp, len(pis_list[0]), ctypes.byref(o), buf, self.proof_size, lens))
+        return [buf.raw[i * self.proof_size:(i + 1) * self.proof_size] for i in range(b)]
+
+    def stage_ms(self):
+        out = (ctypes.c_double * 16)()
+        k = qpgpu().qpgpu_last_stage_ms(out, 16)
+        return list(out[:k])
+
+    def close(self):
+        L = qpgpu()
+        if self.h:
+            L.qpgpu_circuit_destroy(self.h); self.h = None
+        if self.ctx:
+            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gpu_check(rc):
+    if rc != 0:
+        raise RuntimeError("qpgpu error %d: %s" % (rc, qpgpu().qpgpu_last_error().decode()))
+
+
+def rand_felts(rng, shape):
+    """Seeded canonical field elements, with edge values sprinkled in."""
+    a = rng.integers(0, P, size=shape, dtype=np.uint64)
+    flat = a.reshape(-1)
+    edge = np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 32, (1 << 63)], dtype=np.uint64)
+    k = min(len(edge), flat.size)
+    flat[:k] = edge[:k]
+    return a
+
+
+def bitrev_indices(log_n):
+    n = 1 << log_n
+    idx = np.arange(n, dtype=np.uint64)
+    r = np.zeros(n, dtype=np.uint64)
+    for b in range(log_n):
+        r |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(log_n - 1 - b)
+    return r.astype(np.int64)

@@ -1,0 +1,80 @@
+// Per-kernel test hooks (host buffers in, host buffers out). Not part of the drop-in ABI: they exist so tests/ can
+// compare each HIP kernel with its oracle twin bit for bit (SURVEY.md §4 implication (4)).
+#include "kernels.h"
+#include <vector>
+#include <string>
+
+namespace qp { extern thread_local std::string g_last_error; int set_err(int code, const std::string& m); }
+using namespace qp;
+
+#define HOOK_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(-3, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  u64* u() { return (u64*)p; }
+};
+
+extern "C" {
+
+int qpgpu_test_permute(uint64_t* states, size_t count) {
+  DevBuf d; HOOK_CHECK(d.alloc(count * 96));
+  HOOK_CHECK(hipMemcpy(d.p, states, count * 96, hipMemcpyHostToDevice));
+  poseidon_permute_batch(d.u(), count, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(states, d.p, count * 96, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// mode 0: forward DIF (natural in, bit-reversed out); 1: forward DIT (bit-reversed in, natural out);
+// 2: inverse DIF (unscaled); 3: inverse DIT (unscaled). data: [count][n] in place.
+int qpgpu_test_ntt(uint64_t* data, int count, int log_n, int mode) {
+  size_t n = size_t(1) << log_n;
+  DevBuf d, rt; HOOK_CHECK(d.alloc(count * n * 8)); HOOK_CHECK(rt.alloc((n / 2 + 1) * 8));
+  HOOK_CHECK(hipMemcpy(d.p, data, count * n * 8, hipMemcpyHostToDevice));
+  build_root_table(rt.u(), log_n, 0);
+  NttPlan pl{rt.u(), log_n};
+  ntt_inplace(d.u(), n, count, log_n, (mode & 1) != 0, (mode & 2) != 0, nullptr, pl, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(data, d.p, count * n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// coeffs [count][n] -> out [count][n << log_cosets], leaf order, coset shift `shift`.
+int qpgpu_test_lde(const uint64_t* coeffs, int count, int log_n, int log_cosets, uint64_t shift, uint64_t* out) {
+  size_t n = size_t(1) << log_n, N = n << log_cosets; int log_N = log_n + log_cosets;
+  DevBuf in, o, rt, sc; HOOK_CHECK(in.alloc(count * n * 8)); HOOK_CHECK(o.alloc(count * N * 8)); HOOK_CHECK(rt.alloc((N / 2 + 1) * 8)); HOOK_CHECK(sc.alloc(N * 8));
+  HOOK_CHECK(hipMemcpy(in.p, coeffs, count * n * 8, hipMemcpyHostToDevice));
+  build_root_table(rt.u(), log_N, 0);
+  NttPlan pl{rt.u(), log_N};
+  build_lde_scale(sc.u(), log_n, log_cosets, shift, pl, 0);
+  lde_batch(in.u(), n, o.u(), N, count, log_n, log_cosets, sc.u(), pl, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(out, o.p, count * N * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// cols: [width][num_leaves] column-major. digests out: all levels concatenated down to the cap.
+int qpgpu_test_merkle(const uint64_t* cols, int width, size_t num_leaves, int cap_height, uint64_t* digests) {
+  size_t tot = merkle_total_digests(num_leaves, cap_height);
+  DevBuf c, d; HOOK_CHECK(c.alloc((size_t)width * num_leaves * 8)); HOOK_CHECK(d.alloc(tot * 32));
+  HOOK_CHECK(hipMemcpy(c.p, cols, (size_t)width * num_leaves * 8, hipMemcpyHostToDevice));
+  merkle_leaves_colmajor(c.u(), num_leaves, width, num_leaves, d.u(), 0);
+  merkle_levels(d.u(), num_leaves, cap_height, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(digests, d.p, tot * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int qpgpu_test_bitrev(const uint64_t* in, int count, int log_n, uint64_t scale, uint64_t* out) {
+  size_t n = size_t(1) << log_n;
+  DevBuf a, b; HOOK_CHECK(a.alloc(count * n * 8)); HOOK_CHECK(b.alloc(count * n * 8));
+  HOOK_CHECK(hipMemcpy(a.p, in, count * n * 8, hipMemcpyHostToDevice));
+  bitrev_permute(a.u(), n, b.u(), n, count, log_n, scale, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(out, b.p, count * n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+} // extern "C"

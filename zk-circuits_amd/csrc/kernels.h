@@ -1,0 +1,112 @@
+// Internal launcher interface between the host orchestration (qpgpu.hip) and the gfx950 kernels.
+// Everything here enqueues on a HIP stream and never synchronises.
+#pragma once
+#include "gl.h"
+#include <hip/hip_runtime.h>
+
+namespace qp {
+
+// ---------------- NTT / LDE (ntt.hip) ----------------
+// Root table rt[t] = w_M^t for t < M/2, M = 2^log_M >= every transform size used with it.
+struct NttPlan {
+  const u64* rt; int log_M;
+};
+void build_root_table(u64* d_rt, int log_M, hipStream_t s);
+// d_out[i] = shift^i * w_{cosets*n}^{c*i} laid out [c][i] (c natural coset index), for the x`cosets` LDE of n coefficients.
+void build_lde_scale(u64* d_out, int log_n, int log_cosets, u64 shift, const NttPlan& pl, hipStream_t s);
+// d_out[i] = scale * base^i, i < count
+void build_powers(u64* d_out, size_t count, u64 base, u64 scale, hipStream_t s);
+
+// In-place size-2^log_n transforms on `count` columns (column c at data + c*stride).
+//  dit = 0: DIF, natural in -> bit-reversed out.   dit = 1: DIT, bit-reversed in -> natural out.
+//  post (optional, may be null): out[i] *= post[i]  (fused into the last pass).
+void ntt_inplace(u64* data, size_t stride, int count, int log_n, bool dit, bool inverse, const u64* post, const NttPlan& pl, hipStream_t s);
+// Same, reading from `in` and writing to `out` (the source columns are left intact).
+void ntt_copy(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, bool dit, bool inverse, const NttPlan& pl, hipStream_t s);
+// Low-degree extension: for each of `count` coefficient columns (n = 2^log_n coefficients at in + c*in_stride) writes
+// 2^(log_n+log_cosets) values at out + c*out_stride in LEAF order (bit-reversed natural index):
+// block rev(c) holds the size-n DIF transform of coset c. scale = build_lde_scale table.
+void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
+               const u64* scale, const NttPlan& pl, hipStream_t s);
+// out[i] = in[rev(i)] * scale  for `count` columns
+void bitrev_permute(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, u64 scale, hipStream_t s);
+
+// cols[k][L] = salt_value(seed, (oracle*4 + k)*N + L) for k < 4 (salt.h)
+void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
+
+// ---------------- Poseidon / Merkle (merkle.hip) ----------------
+void poseidon_permute_batch(u64* states /*[count][12]*/, size_t count, hipStream_t s);
+// Leaf digests of `num_leaves` rows whose element j sits at cols + j*col_stride + leaf (column-major oracle), width felts per
+// leaf (hash_or_noop). digests: [num_leaves][4].
+void merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, hipStream_t s);
+// FRI layer leaves: leaf L = 2^arity_bits extension values (a[k], b[k]) k in [L*arity, (L+1)*arity), flattened a0,b0,a1,b1...
+void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s);
+// Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to
+// 2^cap_height digests. Returns (host-side) nothing; layout helper below.
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s);
+static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
+  size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
+}
+static inline size_t merkle_total_digests(size_t num_leaves, int cap_height) {
+  size_t t = 0; for (size_t m = num_leaves;; m >>= 1) { t += m; if (m <= (size_t(1) << cap_height)) break; } return t;
+}
+
+} // namespace qp
+
+namespace qp {
+
+// ---------------- PLONK stages (plonk.hip) ----------------
+struct GateDev { u32 tag, sel_index, grp_lo, grp_hi; u64 param; };
+static constexpr int MAX_GATES = 16;
+struct CircuitDev {            // passed by value to kernels
+  int log_n, rate_bits, num_wires, num_routed, num_constants, num_challenges, qdf, num_pp, num_gates, num_selectors;
+  int num_gate_constraints;
+  GateDev gates[MAX_GATES];
+  const u64* k_is;             // device, [num_routed]
+};
+struct Chal2 { u64 v[2]; };
+
+// Z / partial products (row a7). wires_vals [W][n], sigma_vals [R][n] (values on the subgroup), out zpp_vals [nch*(1+npp)][n]
+// ordered [Z_0..Z_{nch-1}, pp_0(npp), pp_1(npp)...]. scratch: q [nch][n][npp+1] + totals [nch][n].
+void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_vals, Chal2 betas, Chal2 gammas, u64* scratch,
+                 u64* zpp_vals, const NttPlan& pl, hipStream_t s);
+static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2); }
+
+// alpha power table: out[c][i] = alpha_c^i, i < count
+void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
+// Quotient values (row a8) on the LDE coset in leaf order: out [nch][N]. cs_lde [S][N], wires_lde [.][N] (stride N), zs_lde [.][N].
+void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
+                   const u64* alpha_pows, int ap_stride, const u64* pi_hash /*host values*/, u64* out, const NttPlan& pl, hipStream_t s);
+
+// out_a[i], out_b[i] = scale * base^i in F_{p^2}, i < count
+void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipStream_t s);
+// Openings (row a9): out[p] = sum_i polys[p][i] * zp[i]  for p < count; out as interleaved (a,b) pairs.
+void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext, hipStream_t s);
+
+// ---------------- FRI (fri.hip) ----------------
+struct PolyGroup { const u64* base; size_t stride; int count; };
+// comp0 = sum_j alpha^j f_j over the 4 oracle coefficient groups in order; comp1 = sum_j alpha^j zs_j (j < nch). Outputs [2][n] each (a then b).
+void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* comp0, u64* comp1, hipStream_t s);
+// final[k] = alpha^nch * Q0[k] + Q1[k], Q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b); tables: zp_b = z_b^i, zi_b = z_b^{-i} (i <= n).
+// scratch: 4*n u64. final: [2][n].
+void fri_divide_combine(const u64* comp0, const u64* comp1, int log_n, const u64* zp0_a, const u64* zp0_b, const u64* zp1_a,
+                        const u64* zp1_b, const u64* zi0_a, const u64* zi0_b, const u64* zi1_a, const u64* zi1_b, Ext alpha_shift,
+                        u64* scratch, u64* final_ab, hipStream_t s);
+// out[i] = sum_{j < 2^arity_bits} beta^j in[(i << arity_bits) + j]   (in: a at in_a, b at in_b; n_out results)
+void fri_fold(const u64* in_a, const u64* in_b, size_t n_out, int arity_bits, Ext beta, u64* out_a, u64* out_b, hipStream_t s);
+// PoW grind (row a12): smallest candidate in [base, base+count) with >= bits leading zeros of permute(state with cand at pos)[7]
+// is atomically min-ed into *result (initialise to ~0).
+struct Sponge12 { u64 s[12]; };
+void pow_grind(Sponge12 st, int pos, u64 base, u64 count, int bits, u64* result, hipStream_t s);
+
+// Query gather (row a13): writes the serialized query rounds for `nq` indices into out (byte buffer).
+static constexpr int MAX_FRI_LAYERS = 8, MAX_QUERIES = 64;
+struct GatherTree { const u64* cols; size_t stride; int width; const u64* digests; };   // initial oracles (column-major, leaf order)
+struct GatherFri { const u64* a; const u64* b; const u64* digests; int arity_bits; int log_leaves; };
+struct GatherArgs {
+  GatherTree trees[4]; int log_N, cap_height, num_layers; GatherFri layers[MAX_FRI_LAYERS];
+  u32 idx[MAX_QUERIES]; int nq; size_t bytes_per_query;
+};
+void query_gather(const GatherArgs& a, uint8_t* out, hipStream_t s);
+
+} // namespace qp

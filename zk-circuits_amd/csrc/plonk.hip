@@ -1,0 +1,282 @@
+// PLONK prover stages on gfx950: Z / partial products, quotient evaluation (a8), openings (a9) —
+// the bodies of qp-plonky2's wires_permutation_partial_products_and_zs, compute_quotient_polys /
+// eval_vanishing_poly_base_batch and OpeningSet::new, behind wormhole/prover/src/lib.rs:233-237.
+// All oracles are column-major ([column][row]) so every per-row/per-point kernel reads coalesced.
+#include "kernels.h"
+#include "poseidon.h"
+#include "../../include/qpgpu.h"
+
+namespace qp {
+
+__device__ __forceinline__ u64 root_pow_d(const u64* rt, int log_M, u64 e) {
+  u64 M = 1ULL << log_M; e &= (M - 1); u64 half = M >> 1;
+  return e < half ? rt[e] : gl_neg(rt[e - half]);
+}
+
+// ------------------------------------------------------------------ Z / partial products
+static constexpr int MAX_CHUNKS = 16;
+
+__global__ void __launch_bounds__(256) k_zpp_rows(CircuitDev cd, const u64* wires, const u64* sigmas, Chal2 betas, Chal2 gammas,
+                                                  u64* q, u64* totals, const u64* rt, int log_M) {
+  const size_t n = size_t(1) << cd.log_n;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = blockIdx.y, nchunks = cd.num_pp + 1, deg = cd.qdf;
+  const u64 beta = betas.v[c], gamma = gammas.v[c];
+  const u64 x = root_pow_d(rt, log_M, (u64)i << (log_M - cd.log_n));
+  const u64 bx = gl_mul(beta, x);
+  u64 nums[MAX_CHUNKS], dens[MAX_CHUNKS];
+  for (int k = 0; k < nchunks; k++) {
+    u64 nu = 1, de = 1;
+    for (int j = k * deg; j < (k + 1) * deg && j < cd.num_routed; j++) {
+      u64 w = wires[(size_t)j * n + i], sg = sigmas[(size_t)j * n + i];
+      nu = gl_mul(nu, gl_add(gl_add(w, gl_mul(bx, cd.k_is[j])), gamma));
+      de = gl_mul(de, gl_add(gl_add(w, gl_mul(beta, sg)), gamma));
+    }
+    nums[k] = nu; dens[k] = de;
+  }
+  // batch inversion of the chunk denominators
+  u64 pref[MAX_CHUNKS]; u64 acc = 1;
+  for (int k = 0; k < nchunks; k++) { pref[k] = acc; acc = gl_mul(acc, dens[k]); }
+  u64 inv = gl_inv(acc), tot = 1;
+  u64* qrow = q + ((size_t)c * n + i) * nchunks;
+  for (int k = nchunks - 1; k >= 0; k--) {
+    u64 dinv = gl_mul(inv, pref[k]); inv = gl_mul(inv, dens[k]);
+    nums[k] = gl_mul(nums[k], dinv);
+  }
+  for (int k = 0; k < nchunks; k++) { qrow[k] = nums[k]; tot = gl_mul(tot, nums[k]); }
+  totals[(size_t)c * n + i] = tot;
+}
+
+// Exclusive prefix product of totals (one block per challenge); result overwrites totals: totals[i] = Z(x_i).
+__global__ void __launch_bounds__(1024) k_zpp_scan(u64* totals, int log_n) {
+  __shared__ u64 sm[1024];
+  const size_t n = size_t(1) << log_n;
+  u64* t = totals + (size_t)blockIdx.x * n;
+  const size_t seg = (n + 1023) / 1024, lo = threadIdx.x * seg, hi = lo + seg < n ? lo + seg : n;
+  u64 acc = 1;
+  for (size_t i = lo; i < hi; i++) acc = gl_mul(acc, t[i]);
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {     // Hillis-Steele inclusive scan (multiplicative)
+    u64 v = threadIdx.x >= off ? sm[threadIdx.x - off] : 1;
+    __syncthreads();
+    sm[threadIdx.x] = gl_mul(sm[threadIdx.x], v);
+    __syncthreads();
+  }
+  u64 run = threadIdx.x ? sm[threadIdx.x - 1] : 1;
+  for (size_t i = lo; i < hi; i++) { u64 v = t[i]; t[i] = run; run = gl_mul(run, v); }
+}
+
+__global__ void __launch_bounds__(256) k_zpp_apply(CircuitDev cd, const u64* q, const u64* totals, u64* zpp) {
+  const size_t n = size_t(1) << cd.log_n;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = blockIdx.y, nchunks = cd.num_pp + 1;
+  u64 acc = totals[(size_t)c * n + i];
+  zpp[(size_t)c * n + i] = acc;
+  const u64* qrow = q + ((size_t)c * n + i) * nchunks;
+  for (int k = 0; k < cd.num_pp; k++) { acc = gl_mul(acc, qrow[k]); zpp[(size_t)(cd.num_challenges + c * cd.num_pp + k) * n + i] = acc; }
+}
+
+void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_vals, Chal2 betas, Chal2 gammas, u64* scratch,
+                 u64* zpp_vals, const NttPlan& pl, hipStream_t s) {
+  const size_t n = size_t(1) << cd.log_n; const int nch = cd.num_challenges, nchunks = cd.num_pp + 1;
+  u64* q = scratch; u64* totals = scratch + (size_t)nch * n * nchunks;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)nch);
+  hipLaunchKernelGGL(k_zpp_rows, grid, dim3(256), 0, s, cd, wires_vals, sigma_vals, betas, gammas, q, totals, pl.rt, pl.log_M);
+  hipLaunchKernelGGL(k_zpp_scan, dim3(nch), dim3(1024), 0, s, totals, cd.log_n);
+  hipLaunchKernelGGL(k_zpp_apply, grid, dim3(256), 0, s, cd, q, totals, zpp_vals);
+}
+
+// ------------------------------------------------------------------ quotient
+__global__ void k_alpha_pows(u64* out, Chal2 alphas, int count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[(size_t)blockIdx.y * count + i] = gl_pow(alphas.v[blockIdx.y], (u64)i);
+}
+void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_alpha_pows, dim3((count + 63) / 64, nch), dim3(64), 0, s, out, alphas, count);
+}
+
+struct Acc2 { u64 a0, a1; };
+// acc += term * alpha^idx for both challenges
+#define ACC_TERM(term_, idx_) do { u64 t__ = (term_); int i__ = (idx_); \
+    g0 = gl_add(g0, gl_mul(t__, ap0[i__])); g1 = gl_add(g1, gl_mul(t__, ap1[i__])); } while (0)
+
+struct Pi4 { u64 v[4]; };
+struct Zh8 { u64 zh[8]; u64 zh_inv[8]; };
+
+__global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __restrict__ cs, const u64* __restrict__ wl,
+                                                  const u64* __restrict__ zl, Chal2 betas, Chal2 gammas,
+                                                  const u64* __restrict__ apw, int ap_stride, Pi4 pih, Zh8 zh, u64 n_inv,
+                                                  u64* __restrict__ out, const u64* __restrict__ rt, int log_M) {
+  const int log_N = cd.log_n + cd.rate_bits;
+  const size_t N = size_t(1) << log_N;
+  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (L >= N) return;
+  const u32 j = rev_bits((u32)L, log_N);
+  const size_t Ln = rev_bits((u32)((j + (1u << cd.rate_bits)) & (N - 1)), log_N);
+  const u64 x = gl_mul(GL_GEN, root_pow_d(rt, log_M, (u64)j << (log_M - log_N)));
+  const int NC = cd.num_constants, R = cd.num_routed, nch = cd.num_challenges, npp = cd.num_pp, deg = cd.qdf;
+  const u64* ap0 = apw; const u64* ap1 = apw + ap_stride;
+  auto Wv = [&](int k) -> u64 { return wl[(size_t)k * N + L]; };
+  u64 tot0 = 0, tot1 = 0;   // running sums for the two challenges
+  int term = 0;
+  // ---- L0(x) (Z_c(x) - 1)
+  {
+    u64 zhx = zh.zh[j & ((1u << cd.rate_bits) - 1)];
+    u64 l0 = gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
+    for (int c = 0; c < nch; c++) {
+      u64 t = gl_mul(l0, gl_sub(zl[(size_t)c * N + L], 1));
+      tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
+    }
+  }
+  // ---- permutation checks
+  for (int c = 0; c < nch; c++) {
+    const u64 beta = betas.v[c], gamma = gammas.v[c], bx = gl_mul(beta, x);
+    u64 prev = zl[(size_t)c * N + L];
+    for (int k = 0; k <= npp; k++) {
+      u64 next = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
+      u64 nu = 1, de = 1;
+      for (int jj = k * deg; jj < (k + 1) * deg && jj < R; jj++) {
+        u64 w = Wv(jj), sg = cs[(size_t)(NC + jj) * N + L];
+        nu = gl_mul(nu, gl_add(gl_add(w, gl_mul(bx, cd.k_is[jj])), gamma));
+        de = gl_mul(de, gl_add(gl_add(w, gl_mul(beta, sg)), gamma));
+      }
+      u64 t = gl_sub(gl_mul(prev, nu), gl_mul(next, de));
+      tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
+      prev = next;
+    }
+  }
+  // ---- gate constraints: sum_g filter_g * sum_j alpha^(term+j) c_{g,j}
+  ap0 += term; ap1 += term;
+  const int nsel = cd.num_selectors;
+  const u64 lc0 = cs[(size_t)nsel * N + L], lc1 = cs[(size_t)(nsel + 1) * N + L];
+  for (int gi = 0; gi < cd.num_gates; gi++) {
+    const GateDev g = cd.gates[gi];
+    const u64 sv = cs[(size_t)g.sel_index * N + L];
+    u64 filter = 1;
+    for (u32 i = g.grp_lo; i < g.grp_hi; i++) if ((int)i != gi) filter = gl_mul(filter, gl_sub((u64)i, sv));
+    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, sv));
+    u64 g0 = 0, g1 = 0;
+    switch (g.tag) {
+      case QPGPU_GATE_NOOP: break;
+      case QPGPU_GATE_CONSTANT:
+        for (u32 i = 0; i < (u32)g.param; i++) ACC_TERM(gl_sub(cs[(size_t)(nsel + i) * N + L], Wv(i)), i);
+        break;
+      case QPGPU_GATE_PUBLIC_INPUT:
+        for (int i = 0; i < 4; i++) ACC_TERM(gl_sub(Wv(i), pih.v[i]), i);
+        break;
+      case QPGPU_GATE_BASESUM2: {
+        const int limbs = (int)g.param;
+        u64 sum = 0;
+        for (int l = limbs - 1; l >= 0; l--) {
+          u64 b = Wv(1 + l);
+          sum = gl_add(gl_add(sum, sum), b);
+          ACC_TERM(gl_mul(b, gl_sub(b, 1)), 1 + l);
+        }
+        ACC_TERM(gl_sub(sum, Wv(0)), 0);
+        break;
+      }
+      case QPGPU_GATE_ARITHMETIC:
+        for (u32 i = 0; i < (u32)g.param; i++) {
+          u64 m0 = Wv(4 * i), m1 = Wv(4 * i + 1), ad = Wv(4 * i + 2), o = Wv(4 * i + 3);
+          ACC_TERM(gl_sub(o, gl_add(gl_mul(lc0, gl_mul(m0, m1)), gl_mul(lc1, ad))), i);
+        }
+        break;
+      case QPGPU_GATE_POSEIDON: {
+        const u64* rc = poseidon_rc();
+        int k = 0;
+        u64 swap = Wv(24);
+        ACC_TERM(gl_mul(swap, gl_sub(swap, 1)), k); k++;
+        u64 st[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          u64 a = Wv(i), b = Wv(i + 4), delta = Wv(25 + i);
+          ACC_TERM(gl_sub(gl_mul(swap, gl_sub(b, a)), delta), k); k++;
+          st[i] = gl_add(a, delta); st[i + 4] = gl_sub(b, delta);
+        }
+#pragma unroll
+        for (int i = 8; i < 12; i++) st[i] = Wv(i);
+        int round = 0;
+        for (int r = 0; r < 4; r++, round++) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+          if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { u64 in = Wv(29 + 12 * (r - 1) + i); ACC_TERM(gl_sub(st[i], in), k); k++; st[i] = in; }
+          }
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
+          mds_layer(st);
+        }
+        for (int r = 0; r < 22; r++, round++) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+          u64 in = Wv(65 + r); ACC_TERM(gl_sub(st[0], in), k); k++;
+          st[0] = sbox7(in);
+          mds_layer(st);
+        }
+        for (int r = 0; r < 4; r++, round++) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+#pragma unroll
+          for (int i = 0; i < 12; i++) { u64 in = Wv(87 + 12 * r + i); ACC_TERM(gl_sub(st[i], in), k); k++; st[i] = in; }
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
+          mds_layer(st);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) { ACC_TERM(gl_sub(st[i], Wv(12 + i)), k); k++; }
+        break;
+      }
+      default: break;   // rejected at circuit creation
+    }
+    tot0 = gl_add(tot0, gl_mul(filter, g0)); tot1 = gl_add(tot1, gl_mul(filter, g1));
+  }
+  const u64 zi = zh.zh_inv[j & ((1u << cd.rate_bits) - 1)];
+  out[L] = gl_mul(tot0, zi);
+  if (nch > 1) out[N + L] = gl_mul(tot1, zi);
+}
+
+void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
+                   const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out, const NttPlan& pl, hipStream_t s) {
+  const int log_N = cd.log_n + cd.rate_bits; const size_t n = size_t(1) << cd.log_n, N = size_t(1) << log_N;
+  Pi4 pih; for (int i = 0; i < 4; i++) pih.v[i] = pi_hash[i];
+  Zh8 zh; u64 gn = gl_pow(GL_GEN, n), w = gl_root(cd.rate_bits), t = 1;
+  for (int k = 0; k < (1 << cd.rate_bits) && k < 8; k++) { zh.zh[k] = gl_sub(gl_mul(gn, t), 1); zh.zh_inv[k] = gl_inv(zh.zh[k]); t = gl_mul(t, w); }
+  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
+                     alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out, pl.rt, pl.log_M);
+}
+
+// ------------------------------------------------------------------ openings
+__global__ void k_ext_powers(u64* oa, u64* ob, size_t count, Ext base, Ext scale) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Ext r = ex_mul(scale, ex_pow(base, i));
+  oa[i] = r.a; ob[i] = r.b;
+}
+void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out_a, out_b, count, base, scale);
+}
+
+__global__ void __launch_bounds__(256) k_open(const u64* polys, size_t stride, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext) {
+  __shared__ u64 sa[256], sb[256];
+  const size_t n = size_t(1) << log_n;
+  const u64* p = polys + (size_t)blockIdx.x * stride;
+  u64 a = 0, b = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) { u64 c = p[i]; a = gl_add(a, gl_mul(c, zp_a[i])); b = gl_add(b, gl_mul(c, zp_b[i])); }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + off]); sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + off]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out_ext[2 * (size_t)blockIdx.x] = sa[0]; out_ext[2 * (size_t)blockIdx.x + 1] = sb[0]; }
+}
+void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_open, dim3((unsigned)count), dim3(256), 0, s, polys, stride, log_n, zp_a, zp_b, out_ext);
+}
+
+} // namespace qp

@@ -1,0 +1,495 @@
+// C-ABI entry points of the MI355X prover backend (include/qpgpu.h): host orchestration of
+// prove_with_partition_witness (SURVEY.md §3.3 stages 1-10; reference call sites wormhole/prover/src/lib.rs:233-237 and
+// wormhole/aggregator/src/circuits/tree.rs:136).
+//
+// Everything heavy (iNTT/LDE, Poseidon Merkle trees, Z/partial products, quotient, openings, FRI combine/fold, PoW grind,
+// query gather) runs as HIP kernels on a per-call stream with a per-call workspace. The Fiat-Shamir transcript
+// (row a6, ~120 sequential Poseidon permutations per proof) is inherently serial, so it runs on the host between
+// stages, exactly where upstream's Challenger runs; each challenge costs one small D2H copy of a cap / opening set.
+#include "../../include/qpgpu.h"
+#include "kernels.h"
+#include "poseidon.h"
+#include <string>
+#include <vector>
+#include <mutex>
+#include <thread>
+#include <atomic>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+
+namespace qp {
+thread_local std::string g_last_error;
+int set_err(int code, const std::string& m) { g_last_error = m; return code; }
+}
+using namespace qp;
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+
+// ---- host-side Challenger (duplex sponge)
+struct Challenger {
+  u64 st[12] = {0}; u64 in[8]; int n_in = 0; u64 out[8]; int n_out = 0;
+  void duplex() { for (int i = 0; i < n_in; i++) st[i] = in[i]; n_in = 0; poseidon_permute(st); for (int i = 0; i < 8; i++) out[i] = st[i]; n_out = 8; }
+  void observe(u64 x) { n_out = 0; in[n_in++] = x; if (n_in == 8) duplex(); }
+  void observe_n(const u64* p, size_t k) { for (size_t i = 0; i < k; i++) observe(p[i]); }
+  u64 challenge() { if (n_in > 0 || n_out == 0) duplex(); return out[--n_out]; }
+  Ext challenge_ext() { u64 a = challenge(); u64 b = challenge(); return ex(a, b); }
+};
+
+struct Layout {   // ProofWithPublicInputs::to_bytes() layout
+  size_t cap_bytes, openings_off, n_openings, fri_caps_off, queries_off, bytes_per_query, final_poly_off, final_poly_len, pow_off, pis_off, total;
+};
+
+struct DevArena {
+  char* base = nullptr; size_t size = 0, used = 0;
+  u64* take(size_t elems) { size_t b = (elems * 8 + 255) & ~size_t(255); char* p = base + used; used += b; return (u64*)p; }
+};
+
+struct Workspace {
+  DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
+  u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
+  u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *comp0, *comp1, *div_scratch, *pow_result;
+  u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
+  uint8_t* query_bytes;
+};
+
+} // namespace
+
+struct qpgpu_ctx { int device; };
+
+struct qpgpu_circuit {
+  qpgpu_ctx* ctx; int device;
+  qpgpu_circuit_desc d; std::vector<qpgpu_gate> gates; std::vector<uint32_t> sel_idx, groups; std::vector<u64> k_is_h;
+  CircuitDev cd; NttPlan pl;
+  int log_n, log_N, rate, S, W, Zp, Q, salt, nch, cap_h, nlayers; size_t n, N;
+  int arity[MAX_FRI_LAYERS]; int fri_log_n[MAX_FRI_LAYERS + 1];   // log2 of coefficient count at each layer
+  u64 *d_rt = nullptr, *d_lde_scale = nullptr, *d_qpost = nullptr, *d_kis = nullptr;
+  u64* d_fri_scale[MAX_FRI_LAYERS + 1] = {nullptr};
+  u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_dig = nullptr;
+  std::vector<u64> cs_cap;
+  Layout lay; size_t ws_bytes = 0;
+  std::mutex mu; std::vector<Workspace*> free_ws;
+};
+
+static int getenv_int(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
+
+// ------------------------------------------------------------------------------------------------ workspace
+static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
+  DevArena& a = w->arena; a.used = 0;
+  const size_t n = c->n, N = c->N; const int s = c->salt;
+  w->wires_vals = a.take((size_t)c->W * n); w->wires_coeffs = a.take((size_t)c->W * n);
+  w->wires_lde = a.take((size_t)(c->W + s) * N); w->wires_dig = a.take(merkle_total_digests(N, c->cap_h) * 4);
+  w->zpp_scratch = a.take(zpp_scratch_elems(c->nch, n, c->d.num_partial_products));
+  w->zs_vals = a.take((size_t)c->Zp * n); w->zs_coeffs = a.take((size_t)c->Zp * n);
+  w->zs_lde = a.take((size_t)(c->Zp + s) * N); w->zs_dig = a.take(merkle_total_digests(N, c->cap_h) * 4);
+  w->q_vals = a.take((size_t)c->nch * N); w->q_lde = a.take((size_t)(c->Q + s) * N); w->q_dig = a.take(merkle_total_digests(N, c->cap_h) * 4);
+  w->alpha_pows = a.take((size_t)c->nch * 256);
+  w->zp0 = a.take(2 * (n + 1)); w->zp1 = a.take(2 * (n + 1)); w->zi0 = a.take(2 * (n + 1)); w->zi1 = a.take(2 * (n + 1));
+  w->openings = a.take(2 * c->lay.n_openings);
+  w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n); w->pow_result = a.take(4);
+  for (int l = 0; l <= c->nlayers; l++) w->fri_coeffs[l] = a.take((size_t)2 << c->fri_log_n[l]);
+  for (int l = 0; l < c->nlayers; l++) {
+    size_t Nl = (size_t)1 << (c->fri_log_n[l] + c->rate);
+    w->fri_vals[l] = a.take(2 * Nl);
+    w->fri_dig[l] = a.take(merkle_total_digests(Nl >> c->arity[l], c->cap_h) * 4);
+  }
+  w->query_bytes = (uint8_t*)a.take((c->lay.bytes_per_query * c->d.fri_num_queries + 7) / 8 + 1);
+  return a.used;
+}
+
+static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->free_ws.empty()) { *out = c->free_ws.back(); c->free_ws.pop_back(); return 0; }
+  }
+  Workspace* w = new Workspace();
+  HIP_TRY(hipSetDevice(c->device));
+  hipError_t e = hipMalloc((void**)&w->arena.base, c->ws_bytes);
+  if (e != hipSuccess) { delete w; return set_err(QPGPU_ERR_OOM, std::string("workspace hipMalloc: ") + hipGetErrorString(e)); }
+  w->arena.size = c->ws_bytes;
+  plan_workspace(c, w);
+  e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_HIP, "hipStreamCreate failed"); }
+  w->pinned_elems = 4096 + 2 * c->lay.n_openings + (c->lay.bytes_per_query * c->d.fri_num_queries) / 8 + 64;
+  e = hipHostMalloc((void**)&w->pinned, w->pinned_elems * 8, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipStreamDestroy(w->stream); (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_OOM, "hipHostMalloc failed"); }
+  *out = w; return 0;
+}
+static void ws_release(qpgpu_circuit* c, Workspace* w) { std::lock_guard<std::mutex> lk(c->mu); c->free_ws.push_back(w); }
+static void ws_destroy(Workspace* w) {
+  if (!w) return;
+  if (w->pinned) (void)hipHostFree(w->pinned);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  if (w->arena.base) (void)hipFree(w->arena.base);
+  delete w;
+}
+
+// Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
+// copied to `cap_host` (pinned) asynchronously.
+static void commit_coeffs(qpgpu_circuit* c, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle, const qpgpu_prove_opts* opts,
+                          u64 salt_seed, const u64* salts_host, u64* cap_host, hipStream_t s) {
+  const size_t N = c->N;
+  lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s);
+  int width = cols;
+  if (c->salt && oracle > 0) {
+    if (salts_host) (void)hipMemcpyAsync(lde + (size_t)cols * N, salts_host + (size_t)(oracle - 1) * 4 * N, 4 * N * 8, hipMemcpyHostToDevice, s);
+    else salt_fill(lde + (size_t)cols * N, N, salt_seed, oracle - 1, s);
+    width += 4;
+  }
+  merkle_leaves_colmajor(lde, N, width, N, dig, s);
+  merkle_levels(dig, N, c->cap_h, s);
+  size_t cap_off = merkle_total_digests(N, c->cap_h) - (size_t(1) << c->cap_h);
+  if (cap_host) (void)hipMemcpyAsync(cap_host, dig + cap_off * 4, (size_t(32)) << c->cap_h, hipMemcpyDeviceToHost, s);
+}
+// values [cols][n] (natural order) -> coefficients [cols][n]; `tmp` needs cols*n elements and is clobbered.
+static void values_to_coeffs(qpgpu_circuit* c, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
+  ntt_copy(vals, c->n, tmp, c->n, cols, c->log_n, false, true, c->pl, s);             // inverse DIF: bit-reversed, unscaled
+  bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
+}
+
+// ------------------------------------------------------------------------------------------------ API
+extern "C" {
+
+const char* qpgpu_last_error(void) { return g_last_error.c_str(); }
+int qpgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int qpgpu_ctx_create(int device, qpgpu_ctx** out) {
+  if (!out) return set_err(QPGPU_ERR_ARG, "null out");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return set_err(QPGPU_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return set_err(QPGPU_ERR_ARG, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return set_err(QPGPU_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  HIP_TRY(hipSetDevice(device));
+  *out = new qpgpu_ctx{device};
+  return 0;
+}
+void qpgpu_ctx_destroy(qpgpu_ctx* ctx) { delete ctx; }
+
+void qpgpu_circuit_destroy(qpgpu_circuit* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (Workspace* w : c->free_ws) ws_destroy(w);
+  for (u64* p : {c->d_rt, c->d_lde_scale, c->d_qpost, c->d_kis, c->d_cs_vals, c->d_cs_coeffs, c->d_cs_lde, c->d_cs_dig}) if (p) (void)hipFree(p);
+  for (int l = 0; l <= MAX_FRI_LAYERS; l++) if (c->d_fri_scale[l]) (void)hipFree(c->d_fri_scale[l]);
+  delete c;
+}
+
+int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_circuit** out) {
+  if (!ctx || !desc || !out) return set_err(QPGPU_ERR_ARG, "null argument");
+  const qpgpu_circuit_desc& d = *desc;
+  if (d.degree_bits < 2 || d.degree_bits + d.fri_rate_bits > 28) return set_err(QPGPU_ERR_ARG, "degree_bits out of range");
+  if (d.num_challenges < 1 || d.num_challenges > 2) return set_err(QPGPU_ERR_ARG, "num_challenges must be 1 or 2");
+  if (d.num_gates > MAX_GATES || d.num_gates == 0) return set_err(QPGPU_ERR_ARG, "bad gate count");
+  if (d.fri_num_layers > MAX_FRI_LAYERS) return set_err(QPGPU_ERR_ARG, "too many FRI layers");
+  if (d.fri_num_queries > MAX_QUERIES) return set_err(QPGPU_ERR_ARG, "too many FRI queries");
+  if (d.fri_rate_bits < 1 || d.fri_rate_bits > 3 || (1u << d.fri_rate_bits) != d.quotient_degree_factor)
+    return set_err(QPGPU_ERR_ARG, "this backend needs quotient_degree_factor == 2^rate_bits <= 8");
+  if (d.num_partial_products + 1 > 16 || (d.num_partial_products + 1) * d.quotient_degree_factor < d.num_routed) return set_err(QPGPU_ERR_ARG, "bad partial product count");
+  if (d.num_selector_groups < 1 || d.num_constants < d.num_selector_groups + 2) return set_err(QPGPU_ERR_ARG, "bad constants/selectors");
+  if (d.num_challenges * (1 + d.num_partial_products + d.num_gate_constraints) > 2 * 256 || d.num_gate_constraints + 40 > 256) return set_err(QPGPU_ERR_ARG, "too many constraint terms");
+  { uint32_t sum = 0; for (uint32_t i = 0; i < d.fri_num_layers; i++) { if (d.fri_arity_bits[i] < 1 || d.fri_arity_bits[i] > 4) return set_err(QPGPU_ERR_ARG, "FRI arity bits must be 1..4"); sum += d.fri_arity_bits[i]; }
+    if (sum > d.degree_bits) return set_err(QPGPU_ERR_ARG, "FRI reductions exceed degree"); }
+  for (uint32_t i = 0; i < d.num_gates; i++) {
+    uint32_t t = d.gates[i].tag;
+    bool ok = t == QPGPU_GATE_NOOP || t == QPGPU_GATE_CONSTANT || t == QPGPU_GATE_PUBLIC_INPUT || t == QPGPU_GATE_BASESUM2 || t == QPGPU_GATE_ARITHMETIC || t == QPGPU_GATE_POSEIDON;
+    if (!ok) return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(t) + " is not supported by this backend (leaf-circuit gate set only)");
+    if (d.selector_indices[i] >= d.num_selector_groups) return set_err(QPGPU_ERR_ARG, "selector index out of range");
+    if (t == QPGPU_GATE_POSEIDON && d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires");
+    if (t == QPGPU_GATE_BASESUM2 && d.gates[i].param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires");
+    if (t == QPGPU_GATE_ARITHMETIC && 4 * d.gates[i].param > d.num_wires) return set_err(QPGPU_ERR_ARG, "Arithmetic ops exceed wires");
+    if (t == QPGPU_GATE_CONSTANT && d.gates[i].param + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  qpgpu_circuit* c = new qpgpu_circuit();
+  c->ctx = ctx; c->device = ctx->device; c->d = d;
+  c->gates.assign(d.gates, d.gates + d.num_gates); c->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
+  c->groups.assign(d.selector_group_ranges, d.selector_group_ranges + 2 * d.num_selector_groups);
+  c->k_is_h.assign(d.k_is, d.k_is + d.num_routed);
+  c->d.gates = c->gates.data(); c->d.selector_indices = c->sel_idx.data(); c->d.selector_group_ranges = c->groups.data();
+  c->d.k_is = c->k_is_h.data(); c->d.constants_sigmas = nullptr;
+  c->log_n = d.degree_bits; c->rate = d.fri_rate_bits; c->log_N = c->log_n + c->rate; c->n = size_t(1) << c->log_n; c->N = size_t(1) << c->log_N;
+  c->S = d.num_constants + d.num_routed; c->W = d.num_wires; c->nch = d.num_challenges; c->Zp = c->nch * (1 + d.num_partial_products);
+  c->Q = c->nch * d.quotient_degree_factor; c->salt = d.zero_knowledge ? 4 : 0; c->cap_h = d.fri_cap_height; c->nlayers = d.fri_num_layers;
+  if ((size_t(1) << c->cap_h) > c->N) { delete c; return set_err(QPGPU_ERR_ARG, "cap height exceeds tree"); }
+  c->fri_log_n[0] = c->log_n;
+  for (int l = 0; l < c->nlayers; l++) {
+    c->arity[l] = d.fri_arity_bits[l]; c->fri_log_n[l + 1] = c->fri_log_n[l] - c->arity[l];
+    if (c->fri_log_n[l] + c->rate - c->arity[l] < c->cap_h) { delete c; return set_err(QPGPU_ERR_ARG, "FRI layer tree smaller than its cap"); }
+  }
+  // ---- layout
+  Layout& L = c->lay; const size_t capn = size_t(1) << c->cap_h;
+  L.cap_bytes = capn * 32; L.openings_off = 3 * L.cap_bytes;
+  L.n_openings = (size_t)c->S + c->W + 2 * c->nch + (size_t)c->nch * d.num_partial_products + c->Q;
+  L.fri_caps_off = L.openings_off + 16 * L.n_openings; L.queries_off = L.fri_caps_off + (size_t)c->nlayers * L.cap_bytes;
+  { size_t path = c->log_N - c->cap_h; size_t widths[4] = {(size_t)c->S, (size_t)c->W + c->salt, (size_t)c->Zp + c->salt, (size_t)c->Q + c->salt};
+    size_t b = 0; for (int t = 0; t < 4; t++) b += 8 * widths[t] + 1 + 32 * path;
+    for (int l = 0; l < c->nlayers; l++) { size_t fp = c->fri_log_n[l] + c->rate - c->arity[l] - c->cap_h; b += (size_t(16) << c->arity[l]) + 1 + 32 * fp; }
+    L.bytes_per_query = b; }
+  L.final_poly_off = L.queries_off + L.bytes_per_query * d.fri_num_queries; L.final_poly_len = size_t(1) << c->fri_log_n[c->nlayers];
+  L.pow_off = L.final_poly_off + 16 * L.final_poly_len; L.pis_off = L.pow_off + 8; L.total = L.pis_off + 8 + 8 * (size_t)d.num_public_inputs;
+  // ---- device constants
+  hipStream_t s = 0;
+#define CC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(e_); qpgpu_circuit_destroy(c); return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, m); } } while (0)
+  const size_t n = c->n, N = c->N;
+  CC_TRY(hipMalloc((void**)&c->d_rt, (N / 2 + 1) * 8));
+  build_root_table(c->d_rt, c->log_N, s);
+  c->pl = NttPlan{c->d_rt, c->log_N};
+  CC_TRY(hipMalloc((void**)&c->d_lde_scale, N * 8));
+  build_lde_scale(c->d_lde_scale, c->log_n, c->rate, GL_GEN, c->pl, s);
+  c->d_fri_scale[0] = nullptr;
+  { u64 shift = GL_GEN;
+    for (int l = 1; l < c->nlayers; l++) {
+      for (int i = 0; i < c->arity[l - 1]; i++) shift = gl_sqr(shift);
+      size_t Nl = size_t(1) << (c->fri_log_n[l] + c->rate);
+      CC_TRY(hipMalloc((void**)&c->d_fri_scale[l], Nl * 8));
+      build_lde_scale(c->d_fri_scale[l], c->fri_log_n[l], c->rate, shift, c->pl, s);
+    } }
+  CC_TRY(hipMalloc((void**)&c->d_qpost, N * 8));
+  build_powers(c->d_qpost, N, gl_inv(GL_GEN), gl_inv((u64)N), s);
+  CC_TRY(hipMalloc((void**)&c->d_kis, d.num_routed * 8));
+  CC_TRY(hipMemcpy(c->d_kis, d.k_is, d.num_routed * 8, hipMemcpyHostToDevice));
+  // CircuitDev
+  memset(&c->cd, 0, sizeof c->cd);
+  c->cd.log_n = c->log_n; c->cd.rate_bits = c->rate; c->cd.num_wires = c->W; c->cd.num_routed = d.num_routed; c->cd.num_constants = d.num_constants;
+  c->cd.num_challenges = c->nch; c->cd.qdf = d.quotient_degree_factor; c->cd.num_pp = d.num_partial_products; c->cd.num_gates = d.num_gates;
+  c->cd.num_selectors = d.num_selector_groups; c->cd.num_gate_constraints = d.num_gate_constraints; c->cd.k_is = c->d_kis;
+  for (uint32_t i = 0; i < d.num_gates; i++) {
+    uint32_t si = d.selector_indices[i];
+    c->cd.gates[i] = GateDev{d.gates[i].tag, si, d.selector_group_ranges[2 * si], d.selector_group_ranges[2 * si + 1], d.gates[i].param};
+  }
+  // preprocessed oracle: constants/sigmas values -> coeffs -> LDE -> Merkle (kept resident)
+  CC_TRY(hipMalloc((void**)&c->d_cs_vals, (size_t)c->S * n * 8));
+  CC_TRY(hipMalloc((void**)&c->d_cs_coeffs, (size_t)c->S * n * 8));
+  CC_TRY(hipMalloc((void**)&c->d_cs_lde, (size_t)c->S * N * 8));
+  CC_TRY(hipMalloc((void**)&c->d_cs_dig, merkle_total_digests(N, c->cap_h) * 32));
+  CC_TRY(hipMemcpy(c->d_cs_vals, d.constants_sigmas, (size_t)c->S * n * 8, hipMemcpyHostToDevice));
+  values_to_coeffs(c, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
+  c->cs_cap.resize(capn * 4);
+  commit_coeffs(c, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, nullptr, 0, nullptr, nullptr, s);
+  CC_TRY(hipStreamSynchronize(s));
+  CC_TRY(hipGetLastError());
+  { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
+  { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
+  *out = c; return 0;
+}
+
+int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit* c, uint64_t* out_cap) {
+  if (!c || !out_cap) return set_err(QPGPU_ERR_ARG, "null argument");
+  memcpy(out_cap, c->cs_cap.data(), c->cs_cap.size() * 8); return 0;
+}
+size_t qpgpu_proof_size(const qpgpu_circuit* c) { return c ? c->lay.total : 0; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------ prove
+static thread_local double g_stage_ms[16]; static thread_local int g_stage_n = 0;
+extern "C" int qpgpu_last_stage_ms(double* out, int cap) { int k = g_stage_n < cap ? g_stage_n : cap; for (int i = 0; i < k; i++) out[i] = g_stage_ms[i]; return g_stage_n; }
+
+static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64_t* wires, const uint64_t* pis, const qpgpu_prove_opts* opts,
+                     u64 salt_seed, const u64* salts_host, uint8_t* out) {
+  const size_t n = c->n, N = c->N; const qpgpu_circuit_desc& d = c->d; const Layout& L = c->lay;
+  const int nch = c->nch, npp = d.num_partial_products; const size_t capn = size_t(1) << c->cap_h;
+  const bool timing = getenv_int("QPGPU_TIMING", 0) != 0;
+  hipEvent_t ev[16]; int nev = 0;
+  auto mark = [&]() { if (timing && nev < 16) { (void)hipEventCreate(&ev[nev]); (void)hipEventRecord(ev[nev], s); nev++; } };
+  for (uint32_t i = 0; i < d.num_public_inputs; i++) if (pis[i] >= GL_P) return set_err(QPGPU_ERR_WITNESS, "non-canonical public input");
+  u64* pin = w->pinned;
+  mark();
+  // ---- 1/2: witness in, wires commitment
+  const u64* wires_vals = (const u64*)wires;
+  if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
+  u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
+  values_to_coeffs(c, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
+  commit_coeffs(c, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, opts, salt_seed, salts_host, pin, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  mark();
+  memcpy(out, pin, L.cap_bytes);
+  Challenger ch;
+  ch.observe_n((const u64*)d.circuit_digest, 4); ch.observe_n(pi_hash, 4); ch.observe_n(pin, capn * 4);
+  Chal2 betas{{0, 0}}, gammas{{0, 0}}, alphas{{0, 0}};
+  for (int i = 0; i < nch; i++) betas.v[i] = ch.challenge();
+  for (int i = 0; i < nch; i++) gammas.v[i] = ch.challenge();
+  // ---- 4: Z / partial products
+  zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s);
+  values_to_coeffs(c, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
+  commit_coeffs(c, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, opts, salt_seed, salts_host, pin, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  mark();
+  memcpy(out + L.cap_bytes, pin, L.cap_bytes);
+  ch.observe_n(pin, capn * 4);
+  for (int i = 0; i < nch; i++) alphas.v[i] = ch.challenge();
+  // ---- 6: quotient
+  const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
+  alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
+  quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s);
+  ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s);       // coset iNTT: leaf order in, coefficients out
+  commit_coeffs(c, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, opts, salt_seed, salts_host, pin, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  mark();
+  memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
+  ch.observe_n(pin, capn * 4);
+  Ext zeta = ch.challenge_ext();
+  if (ex_eq(ex_pow(zeta, n), ex(1, 0))) return set_err(QPGPU_ERR_ZETA, "zeta lies in the trace subgroup");
+  // ---- 8: openings
+  const Ext gzeta = ex_scale(zeta, gl_root(c->log_n));
+  const Ext zinv = ex_inv(zeta), gzinv = ex_inv(gzeta);
+  u64 *zp0a = w->zp0, *zp0b = w->zp0 + n + 1, *zp1a = w->zp1, *zp1b = w->zp1 + n + 1;
+  u64 *zi0a = w->zi0, *zi0b = w->zi0 + n + 1, *zi1a = w->zi1, *zi1b = w->zi1 + n + 1;
+  ext_powers(zp0a, zp0b, n + 1, zeta, ex(1, 0), s); ext_powers(zp1a, zp1b, n + 1, gzeta, ex(1, 0), s);
+  ext_powers(zi0a, zi0b, n + 1, zinv, ex(1, 0), s); ext_powers(zi1a, zi1b, n + 1, gzinv, ex(1, 0), s);
+  {
+    u64* o = w->openings;   // proof order: constants|sigmas (S), wires (W), zs (nch), zs_next (nch), pp (nch*npp), quotient (Q)
+    open_polys(c->d_cs_coeffs, n, c->S, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)c->S;
+    open_polys(w->wires_coeffs, n, c->W, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)c->W;
+    open_polys(w->zs_coeffs, n, nch, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)nch;
+    open_polys(w->zs_coeffs, n, nch, c->log_n, zp1a, zp1b, o, s); o += 2 * (size_t)nch;
+    open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)nch * npp;
+    open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, o, s);
+  }
+  HIP_TRY(hipMemcpyAsync(pin, w->openings, 16 * L.n_openings, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  mark();
+  memcpy(out + L.openings_off, pin, 16 * L.n_openings);
+  {
+    const size_t a = 2 * ((size_t)c->S + c->W + nch);          // constants..zs
+    ch.observe_n(pin, a);
+    ch.observe_n(pin + a + 2 * nch, 2 * ((size_t)nch * npp + c->Q));   // partial products, quotient
+    ch.observe_n(pin + a, 2 * (size_t)nch);                    // zs_next
+  }
+  // ---- 9: FRI
+  const Ext fa = ch.challenge_ext();
+  fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
+              PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->comp0, w->comp1, s);
+  fri_divide_combine(w->comp0, w->comp1, c->log_n, zp0a, zp0b, zp1a, zp1b, zi0a, zi0b, zi1a, zi1b, ex_pow(fa, nch), w->div_scratch, w->fri_coeffs[0], s);
+  Ext fri_betas[MAX_FRI_LAYERS];
+  for (int l = 0; l < c->nlayers; l++) {
+    const int lg = c->fri_log_n[l]; const size_t nl = size_t(1) << lg, Nl = nl << c->rate;
+    lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s);
+    const size_t leaves = Nl >> c->arity[l];
+    merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
+    merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
+    size_t cap_off = merkle_total_digests(leaves, c->cap_h) - capn;
+    HIP_TRY(hipMemcpyAsync(pin, w->fri_dig[l] + cap_off * 4, L.cap_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
+    ch.observe_n(pin, capn * 4);
+    fri_betas[l] = ch.challenge_ext();
+    const size_t nn = nl >> c->arity[l];
+    fri_fold(w->fri_coeffs[l], w->fri_coeffs[l] + nl, nn, c->arity[l], fri_betas[l], w->fri_coeffs[l + 1], w->fri_coeffs[l + 1] + nn, s);
+  }
+  {
+    const size_t fl = L.final_poly_len;
+    HIP_TRY(hipMemcpyAsync(pin, w->fri_coeffs[c->nlayers], 2 * fl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    u64* fp = (u64*)(out + L.final_poly_off);
+    for (size_t i = 0; i < fl; i++) { u64 a = pin[i], b = pin[fl + i]; memcpy(&fp[2 * i], &a, 8); memcpy(&fp[2 * i + 1], &b, 8); ch.observe(a); ch.observe(b); }
+  }
+  mark();
+  // ---- PoW
+  u64 pow_witness;
+  if (opts && opts->have_pow_witness) pow_witness = opts->pow_witness;
+  else {
+    Sponge12 sp; for (int i = 0; i < 12; i++) sp.s[i] = ch.st[i];
+    for (int i = 0; i < ch.n_in; i++) sp.s[i] = ch.in[i];
+    const int pos = ch.n_in;
+    u64 none = ~0ULL; pow_witness = none;
+    HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s));
+    u64 base = 0, span = 1ULL << 18;
+    for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
+      pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s);
+      HIP_TRY(hipMemcpyAsync(pin, w->pow_result, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      pow_witness = pin[0]; base += span; if (span < (1ULL << 26)) span <<= 1;
+    }
+    if (pow_witness == none) return set_err(QPGPU_ERR_POW, "proof-of-work grind found no witness");
+  }
+  ch.observe(pow_witness);
+  {
+    u64 resp = ch.challenge();
+    int lz = resp == 0 ? 64 : __builtin_clzll(resp);
+    if (lz < (int)d.fri_pow_bits) return set_err(QPGPU_ERR_POW, "supplied pow_witness does not meet proof_of_work_bits");
+  }
+  memcpy(out + L.pow_off, &pow_witness, 8);
+  mark();
+  // ---- queries
+  GatherArgs ga; memset(&ga, 0, sizeof ga);
+  ga.trees[0] = GatherTree{c->d_cs_lde, N, c->S, c->d_cs_dig};
+  ga.trees[1] = GatherTree{w->wires_lde, N, c->W + c->salt, w->wires_dig};
+  ga.trees[2] = GatherTree{w->zs_lde, N, c->Zp + c->salt, w->zs_dig};
+  ga.trees[3] = GatherTree{w->q_lde, N, c->Q + c->salt, w->q_dig};
+  ga.log_N = c->log_N; ga.cap_height = c->cap_h; ga.num_layers = c->nlayers;
+  for (int l = 0; l < c->nlayers; l++) {
+    const size_t Nl = size_t(1) << (c->fri_log_n[l] + c->rate);
+    ga.layers[l] = GatherFri{w->fri_vals[l], w->fri_vals[l] + Nl, w->fri_dig[l], c->arity[l], c->fri_log_n[l] + c->rate - c->arity[l]};
+  }
+  ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query;
+  for (int q = 0; q < ga.nq; q++) ga.idx[q] = (u32)(ch.challenge() % N);
+  query_gather(ga, w->query_bytes, s);
+  HIP_TRY(hipMemcpyAsync(pin, w->query_bytes, L.bytes_per_query * ga.nq, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  memcpy(out + L.queries_off, pin, L.bytes_per_query * ga.nq);
+  { u64 npi = d.num_public_inputs; memcpy(out + L.pis_off, &npi, 8); memcpy(out + L.pis_off + 8, pis, 8 * npi); }
+  mark();
+  if (timing) {
+    g_stage_n = nev - 1;
+    for (int i = 0; i + 1 < nev; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); g_stage_ms[i] = ms; }
+    for (int i = 0; i < nev; i++) (void)hipEventDestroy(ev[i]);
+  }
+  return 0;
+}
+
+extern "C" {
+
+int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
+                const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len) {
+  if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");
+  if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
+  if (out_cap < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "output buffer too small: need " + std::to_string(c->lay.total));
+  HIP_TRY(hipSetDevice(c->device));
+  Workspace* w = nullptr; int rc = ws_acquire(c, &w); if (rc) return rc;
+  hipStream_t s = (opts && opts->stream) ? (hipStream_t)opts->stream : w->stream;
+  rc = prove_one(c, w, s, wires, public_inputs, opts, opts ? opts->salt_seed : 0, opts ? opts->salts : nullptr, out);
+  if (rc != 0) (void)hipStreamSynchronize(s);
+  ws_release(c, w);
+  if (rc == 0 && out_len) *out_len = c->lay.total;
+  return rc;
+}
+
+int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wires, const uint64_t* const* public_inputs,
+                      size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride, size_t* out_lens) {
+  if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");
+  if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
+  if (out_stride < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "out_stride smaller than proof size");
+  if (batch == 0) return 0;
+  int workers = getenv_int("QPGPU_STREAMS", 4); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
+  std::atomic<size_t> next(0); std::atomic<int> first_rc(0); std::mutex emu; std::string emsg;
+  auto body = [&]() {
+    if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
+    Workspace* w = nullptr; int rc = ws_acquire(c, &w);
+    if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
+    for (;;) {
+      size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
+      qpgpu_prove_opts o; if (opts) o = *opts; else memset(&o, 0, sizeof o);
+      o.stream = nullptr;
+      const u64* salts = (opts && opts->salts) ? opts->salts + i * 3 * 4 * c->N : nullptr;
+      rc = prove_one(c, w, w->stream, wires[i], public_inputs[i], &o, o.salt_seed + i, salts, out + i * out_stride);
+      if (rc) { (void)hipStreamSynchronize(w->stream); std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
+      if (out_lens) out_lens[i] = c->lay.total;
+    }
+    ws_release(c, w);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < workers; t++) th.emplace_back(body);
+  body();
+  for (auto& t : th) t.join();
+  if (first_rc.load()) return set_err(first_rc.load(), emsg);
+  return 0;
+}
+
+} // extern "C"
