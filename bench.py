@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: wormhole proofs/s on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path (prove_with_partition_witness through the qpgpu C-ABI) over one synthetic witness of the
+configured circuit, witness already resident in HBM. Default workload = BASELINE configs[1]: single wormhole-shaped
+proof, zk config, degree 2^14 ("B"). With N ranks every rank proves its own independent witnesses (weak scaling, no
+data-path collective); after the K steps the fixed-size proof blobs are all-gathered over RCCL (the exchange that
+precedes the aggregator step) inside the timed region.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="B", help="A: leaf non-zk 2^13, B: leaf zk 2^14 (default), V: voting-shaped 2^20")
+    ap.add_argument("--batch", type=int, default=1, help=">1: each step is one stream-pipelined batch (BASELINE configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-proofs", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import harness as H
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- circuit (resident) + synthetic witnesses resident in HBM (outside the timed region)
+    sc = H.SynthCircuit(args.preset)
+    gc = H.GpuCircuit(sc.desc, device=local_rank)
+    L = H.qpgpu()
+    L.qpgpu_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.qpgpu_profile_name.restype = ctypes.c_char_p
+    nwit = min(4, max(1, args.batch)) if args.batch > 1 else 4
+    nwit = max(nwit, min(args.batch, 8))
+    seeds = [0x51570000 + rank * 64 + i for i in range(nwit)]
+    wit_dev, pis_list = [], []
+    for sd in seeds:
+        w, p = sc.witness(sd)
+        wit_dev.append(torch.from_numpy(w.view(np.int64)).to(dev))
+        pis_list.append(p)
+    torch.cuda.synchronize()
+
+    def step(i):
+        if args.batch == 1:
+            k = i % nwit
+            return [gc.prove(None, pis_list[k], salt_seed=seeds[k], wires_dev_ptr=wit_dev[k].data_ptr())]
+        ptrs = [wit_dev[(i * args.batch + j) % nwit].data_ptr() for j in range(args.batch)]
+        pl = [pis_list[(i * args.batch + j) % nwit] for j in range(args.batch)]
+        return gc.prove_batch(ptrs, pl, salt_seed=seeds[0] + i * args.batch, wires_on_device=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    L.qpgpu_profile_reset()
+    L.qpgpu_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    proofs = []
+    for i in range(args.steps):
+        proofs += step(i)
+    if dist is not None:
+        blob = torch.from_numpy(np.frombuffer(b"".join(proofs), dtype=np.uint8).copy()).to(dev)
+        gathered = [torch.empty_like(blob) for _ in range(world)]
+        dist.all_gather(gathered, blob)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.qpgpu_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel-group timing -> roofline of the dominant kernel
+    kernels = {}
+    for kid in range(L.qpgpu_profile_count()):
+        n_l, ms, by = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        L.qpgpu_profile_get(kid, ctypes.byref(n_l), ctypes.byref(ms), ctypes.byref(by))
+        if n_l.value:
+            kernels[L.qpgpu_profile_name(kid).decode()] = {"launches": n_l.value, "avg_ms": ms.value / n_l.value,
+                                                          "total_ms": ms.value, "alg_bytes_per_launch": by.value / n_l.value}
+    roofline = None
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        kd = kernels[dom]
+        achieved = kd["alg_bytes_per_launch"] / (kd["avg_ms"] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes (if collected)
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.preset, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                    "note": "Poseidon leaf hashing is integer-VALU-bound, not HBM-bound (DESIGN.md §4); frac is still quoted against HBM peak",
+                    "avg_launch_ms": round(kd["avg_ms"], 4), "alg_bytes_per_launch": kd["alg_bytes_per_launch"]}
+
+    nproofs = args.steps * args.batch * world
+    out = {
+        "metric": "wormhole proofs/s", "value": round(nproofs / dt, 3), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64 (Goldilocks field, 64-bit modular integer)", "data": "synthetic",
+        "config": {"workload": {"A": "single wormhole-shaped leaf proof, non-zk, degree 2^13 (BASELINE configs[1] shape of the reference tests)",
+                                "B": "single wormhole-shaped leaf proof, zk config, degree 2^14 (BASELINE configs[1])",
+                                "V": "voting-shaped proof at 2^20 rows (BASELINE configs[4])"}.get(args.preset, args.preset),
+                   "preset": args.preset, "proofs_per_step": args.batch, "degree_bits": int(sc.desc.degree_bits),
+                   "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
+                   "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
+        "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
+        "roofline": roofline, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+    }
+
+    # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        oc = H.OracleCircuit(sc.desc)
+        cores = H.oracle().orc_max_threads()
+        w0, p0 = sc.witness(seeds[0])
+        salts = sc.salts(seeds[0]) if sc.desc.zero_knowledge else None
+        oc.prove(w0, p0, salts)                      # warm (twiddle tables, page faults)
+        t1 = time.perf_counter()
+        for _ in range(args.cpu_proofs):
+            cpu_pf = oc.prove(w0, p0, salts)
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(args.cpu_proofs / cdt, 4), "unit": "proofs/s", "cores": cores, "kind": "port",
+                               "sample": "%d proofs of the same circuit/witness by oracle/ (C++ restatement of qp-plonky2's prover, OpenMP); "
+                                         "the Rust reference cannot be built here (no cargo, crates not on disk)" % args.cpu_proofs,
+                               "ms_per_proof": round(cdt / args.cpu_proofs * 1e3, 2)}
+        out["bit_exact_vs_cpu"] = bool(cpu_pf == gc.prove(None, p0, salt_seed=seeds[0], wires_dev_ptr=wit_dev[0].data_ptr()))
+    if rank == 0:
+        print(json.dumps(out))
+    gc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

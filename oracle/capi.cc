@@ -17,6 +17,7 @@ extern "C" {
 const char* orc_last_error() { return g_err.c_str(); }
 void orc_round_constants(u64* out) { memcpy(out, poseidon_round_constants(), 360 * 8); }
 void orc_permute(u64* st) { poseidon_permute(st); }
+void orc_permute_generic(u64* st) { poseidon_permute_generic(st); }
 void orc_hash_no_pad(const u64* x, size_t len, u64* out) { Hash h = hash_no_pad(x, len); memcpy(out, h.data(), 32); }
 void orc_hash_or_noop(const u64* x, size_t len, u64* out) { Hash h = hash_or_noop(x, len); memcpy(out, h.data(), 32); }
 void orc_two_to_one(const u64* l, const u64* r, u64* out) { Hash a, b; memcpy(a.data(), l, 32); memcpy(b.data(), r, 32); Hash h = two_to_one(a, b); memcpy(out, h.data(), 32); }

@@ -1,0 +1,14 @@
+"""zk-circuits_amd — MI355X (gfx950) native Plonky2 prover backend for the Quantus wormhole / voting circuits.
+
+Host-side mirror of the reference's drop-in API for the hot path:
+  WormholeProver.{new, commit, prove}        (/root/reference/wormhole/prover/src/lib.rs:190-237)
+  WormholeProofAggregator.{push_proof, aggregate}  (/root/reference/wormhole/aggregator/src/aggregator.rs:28-92)
+on top of the C-ABI in include/qpgpu.h (libqpgpu.so: hand-written HIP kernels). The directory name contains a hyphen;
+import it with importlib.import_module("zk-circuits_amd").
+
+The product path never touches oracle/ and has no CPU fallback: loading fails loudly if libqpgpu.so is missing.
+"""
+from .ffi import lib, QpgpuError, CircuitDesc, ProveOpts, Gate  # noqa: F401
+from .prover import (CircuitConfig, CircuitInputs, ProofWithPublicInputs, WormholeProver,  # noqa: F401
+                     WormholeCircuitData)
+from .aggregator import WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves  # noqa: F401

@@ -1,0 +1,102 @@
+"""WormholeProofAggregator mirror (reference: /root/reference/wormhole/aggregator/src/aggregator.rs:13-92,
+circuits/tree.rs:24-103, util.rs:11-29).
+
+Scope this round: the buffer semantics and error behaviour of push_proof / aggregate, the
+sharding of independent leaf proofs (one per GPU stream / per rank) and the RCCL gather of the fixed-size proof blobs
+that precedes the aggregator step. The recursive-verifier circuit itself needs gates outside the leaf set
+("next" rank 1), so `aggregate()` returns the gathered, padded leaf set rather than a root proof.
+"""
+import ctypes
+import numpy as np
+from . import ffi
+from .prover import ProofWithPublicInputs
+
+DEFAULT_TREE_BRANCHING_FACTOR = 2   # tree.rs:17
+DEFAULT_TREE_DEPTH = 3              # tree.rs:20
+
+
+class TreeAggregationConfig:
+    def __init__(self, tree_branching_factor=DEFAULT_TREE_BRANCHING_FACTOR, tree_depth=DEFAULT_TREE_DEPTH):
+        self.tree_branching_factor = tree_branching_factor
+        self.tree_depth = tree_depth
+        self.num_leaf_proofs = tree_branching_factor ** tree_depth
+
+
+class AggregatedLeaves:
+    """What the aggregator step consumes: num_leaf_proofs proof blobs (real ones first, dummy padding after) and the
+    concatenated leaf public inputs (the root proof's public inputs in the reference, tree.rs:122)."""
+
+    def __init__(self, proofs, num_real):
+        self.proofs = proofs
+        self.num_real = num_real
+        self.public_inputs = [x for p in proofs for x in p.public_inputs]
+
+
+class WormholeProofAggregator:
+    def __init__(self, leaf_circuit_data, config=None):
+        self.leaf_circuit_data = leaf_circuit_data
+        self.config = config or TreeAggregationConfig()
+        self.proofs_buffer = []
+
+    def with_config(self, config):
+        self.config = config
+        return self
+
+    def push_proof(self, proof):
+        if self.proofs_buffer is None:
+            self.proofs_buffer = [proof]
+            return
+        if len(self.proofs_buffer) >= self.config.num_leaf_proofs:
+            raise RuntimeError("tried to add proof when proof buffer is full")
+        self.proofs_buffer.append(proof)
+
+    def prove_leaves(self, circuit_inputs_list, salt_seed=0):
+        """Proves independent leaf witnesses as one stream-pipelined batch on this GPU (qpgpu_prove_batch) and pushes them."""
+        cd = self.leaf_circuit_data
+        ws, ps = zip(*[cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs) for ci in circuit_inputs_list])
+        b = len(ws)
+        wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in ws])
+        pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for p in ps])
+        o = ffi.ProveOpts()
+        o.salt_seed = salt_seed
+        buf = ctypes.create_string_buffer(cd.proof_size * b)
+        lens = (ctypes.c_size_t * b)()
+        ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf,
+                                              cd.proof_size, lens))
+        for i in range(b):
+            self.push_proof(ProofWithPublicInputs(buf.raw[i * cd.proof_size:(i + 1) * cd.proof_size], cd.num_public_inputs))
+
+    def aggregate(self, dummy_proof=None):
+        if self.proofs_buffer is None:
+            raise RuntimeError("there are no proofs to aggregate")
+        proofs, self.proofs_buffer = self.proofs_buffer, None
+        if len(proofs) > self.config.num_leaf_proofs:
+            raise RuntimeError("proofs to aggregate was more than the maximum allowed")
+        num_real = len(proofs)
+        if num_real < self.config.num_leaf_proofs:
+            if dummy_proof is None:
+                if not proofs:
+                    raise RuntimeError("failed to deserialize dummy proof")
+                dummy_proof = proofs[0]
+            proofs = proofs + [dummy_proof] * (self.config.num_leaf_proofs - num_real)
+        return AggregatedLeaves(proofs, num_real)
+
+
+def gather_proofs(local_proofs, proof_size, group=None, device=None):
+    """All ranks contribute their fixed-size proof blobs; every rank gets the concatenation in rank order.
+    torch.distributed all_gather over RCCL (backend "nccl") on GPU tensors, gloo on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+    k = len(local_proofs)
+    flat = np.frombuffer(b"".join(local_proofs), dtype=np.uint8).copy() if k else np.zeros(0, dtype=np.uint8)
+    t = torch.from_numpy(flat)
+    if device is not None:
+        t = t.to(device)
+    world = dist.get_world_size(group)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    res = []
+    for o in outs:
+        raw = o.cpu().numpy().tobytes()
+        res += [raw[i * proof_size:(i + 1) * proof_size] for i in range(k)]
+    return res

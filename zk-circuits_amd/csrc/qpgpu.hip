@@ -47,7 +47,17 @@ struct DevArena {
   u64* take(size_t elems) { size_t b = (elems * 8 + 255) & ~size_t(255); char* p = base + used; used += b; return (u64*)p; }
 };
 
+// ---- optional per-kernel-group timing (HIP events on the proving stream), used by bench.py for the roofline object
+enum ProfId { PF_INTT = 0, PF_LDE, PF_LEAVES, PF_LEVELS, PF_ZPP, PF_QUOTIENT, PF_QUOTIENT_INTT, PF_OPENINGS, PF_FRI_COMBINE,
+              PF_FRI_LAYERS, PF_POW, PF_GATHER, PF_COUNT };
+const char* const PROF_NAMES[PF_COUNT] = {"intt_values_to_coeffs", "lde_batch", "merkle_leaves_colmajor", "merkle_levels", "z_partial_products",
+                                          "quotient_eval", "quotient_coset_intt", "openings", "fri_compose_divide", "fri_layers", "pow_grind", "query_gather"};
+struct ProfAcc { uint64_t launches = 0; double ms = 0, bytes = 0; };
+std::atomic<int> g_prof_on(0); std::mutex g_prof_mu; ProfAcc g_prof[PF_COUNT];
+static constexpr int PROF_EVENTS = 128;
+
 struct Workspace {
+  hipEvent_t pev[PROF_EVENTS]; int pev_made = 0, pev_used = 0; int pev_id[PROF_EVENTS / 2]; double pev_bytes[PROF_EVENTS / 2];
   DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *comp0, *comp1, *div_scratch, *pow_result;
@@ -72,6 +82,26 @@ struct qpgpu_circuit {
   Layout lay; size_t ws_bytes = 0;
   std::mutex mu; std::vector<Workspace*> free_ws;
 };
+
+struct ProfScope {   // records an event pair around the launches made inside its lifetime
+  Workspace* w; hipStream_t s; bool on;
+  ProfScope(Workspace* w_, hipStream_t s_, int id, double bytes) : w(w_), s(s_), on(false) {
+    if (!g_prof_on.load(std::memory_order_relaxed) || w->pev_used + 2 > PROF_EVENTS) return;
+    while (w->pev_made < w->pev_used + 2) { if (hipEventCreate(&w->pev[w->pev_made]) != hipSuccess) return; w->pev_made++; }
+    on = true; w->pev_id[w->pev_used / 2] = id; w->pev_bytes[w->pev_used / 2] = bytes;
+    (void)hipEventRecord(w->pev[w->pev_used], s);
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(w->pev[w->pev_used + 1], s); w->pev_used += 2; } }
+};
+static void prof_flush(Workspace* w) {   // call after the stream has been synchronised
+  if (!w->pev_used) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < w->pev_used; i += 2) {
+    float ms = 0; if (hipEventElapsedTime(&ms, w->pev[i], w->pev[i + 1]) != hipSuccess) continue;
+    ProfAcc& a = g_prof[w->pev_id[i / 2]]; a.launches++; a.ms += ms; a.bytes += w->pev_bytes[i / 2];
+  }
+  w->pev_used = 0;
+}
 
 static int getenv_int(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
 
@@ -120,6 +150,7 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
 static void ws_release(qpgpu_circuit* c, Workspace* w) { std::lock_guard<std::mutex> lk(c->mu); c->free_ws.push_back(w); }
 static void ws_destroy(Workspace* w) {
   if (!w) return;
+  for (int i = 0; i < w->pev_made; i++) (void)hipEventDestroy(w->pev[i]);
   if (w->pinned) (void)hipHostFree(w->pinned);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   if (w->arena.base) (void)hipFree(w->arena.base);
@@ -128,23 +159,27 @@ static void ws_destroy(Workspace* w) {
 
 // Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
 // copied to `cap_host` (pinned) asynchronously.
-static void commit_coeffs(qpgpu_circuit* c, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle, const qpgpu_prove_opts* opts,
+static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle, const qpgpu_prove_opts* opts,
                           u64 salt_seed, const u64* salts_host, u64* cap_host, hipStream_t s) {
   const size_t N = c->N;
-  lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s);
+  { ProfScope ps(w, s, PF_LDE, 8.0 * cols * (c->n + N));
+    lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s); }
   int width = cols;
   if (c->salt && oracle > 0) {
     if (salts_host) (void)hipMemcpyAsync(lde + (size_t)cols * N, salts_host + (size_t)(oracle - 1) * 4 * N, 4 * N * 8, hipMemcpyHostToDevice, s);
     else salt_fill(lde + (size_t)cols * N, N, salt_seed, oracle - 1, s);
     width += 4;
   }
-  merkle_leaves_colmajor(lde, N, width, N, dig, s);
-  merkle_levels(dig, N, c->cap_h, s);
+  { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
+    merkle_leaves_colmajor(lde, N, width, N, dig, s); }
+  { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
+    merkle_levels(dig, N, c->cap_h, s); }
   size_t cap_off = merkle_total_digests(N, c->cap_h) - (size_t(1) << c->cap_h);
   if (cap_host) (void)hipMemcpyAsync(cap_host, dig + cap_off * 4, (size_t(32)) << c->cap_h, hipMemcpyDeviceToHost, s);
 }
 // values [cols][n] (natural order) -> coefficients [cols][n]; `tmp` needs cols*n elements and is clobbered.
-static void values_to_coeffs(qpgpu_circuit* c, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
+static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
+  ProfScope ps(w, s, PF_INTT, 8.0 * cols * c->n * 2);
   ntt_copy(vals, c->n, tmp, c->n, cols, c->log_n, false, true, c->pl, s);             // inverse DIF: bit-reversed, unscaled
   bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
 }
@@ -268,10 +303,12 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   CC_TRY(hipMalloc((void**)&c->d_cs_lde, (size_t)c->S * N * 8));
   CC_TRY(hipMalloc((void**)&c->d_cs_dig, merkle_total_digests(N, c->cap_h) * 32));
   CC_TRY(hipMemcpy(c->d_cs_vals, d.constants_sigmas, (size_t)c->S * n * 8, hipMemcpyHostToDevice));
-  values_to_coeffs(c, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
+  Workspace* nows = new Workspace();   // no profiling events for the one-off preprocessing
+  values_to_coeffs(c, nows, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
   c->cs_cap.resize(capn * 4);
-  commit_coeffs(c, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, nullptr, 0, nullptr, nullptr, s);
+  commit_coeffs(c, nows, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, nullptr, 0, nullptr, nullptr, s);
   CC_TRY(hipStreamSynchronize(s));
+  nows->pev_used = 0; ws_destroy(nows);
   CC_TRY(hipGetLastError());
   { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
@@ -304,8 +341,8 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const u64* wires_vals = (const u64*)wires;
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
-  values_to_coeffs(c, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
-  commit_coeffs(c, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, opts, salt_seed, salts_host, pin, s);
+  values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
+  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, opts, salt_seed, salts_host, pin, s);
   HIP_TRY(hipStreamSynchronize(s));
   mark();
   memcpy(out, pin, L.cap_bytes);
@@ -315,9 +352,10 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   for (int i = 0; i < nch; i++) betas.v[i] = ch.challenge();
   for (int i = 0; i < nch; i++) gammas.v[i] = ch.challenge();
   // ---- 4: Z / partial products
-  zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s);
-  values_to_coeffs(c, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
-  commit_coeffs(c, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, opts, salt_seed, salts_host, pin, s);
+  { ProfScope ps(w, s, PF_ZPP, 8.0 * n * (2.0 * d.num_routed + c->Zp));
+    zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
+  values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
+  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, opts, salt_seed, salts_host, pin, s);
   HIP_TRY(hipStreamSynchronize(s));
   mark();
   memcpy(out + L.cap_bytes, pin, L.cap_bytes);
@@ -326,9 +364,11 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   // ---- 6: quotient
   const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
   alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
-  quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s);
-  ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s);       // coset iNTT: leaf order in, coefficients out
-  commit_coeffs(c, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, opts, salt_seed, salts_host, pin, s);
+  { ProfScope ps(w, s, PF_QUOTIENT, 8.0 * N * (c->S + c->W + c->Zp + 2 * nch));
+    quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
+  { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
+    ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
+  commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, opts, salt_seed, salts_host, pin, s);
   HIP_TRY(hipStreamSynchronize(s));
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
@@ -340,6 +380,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const Ext zinv = ex_inv(zeta), gzinv = ex_inv(gzeta);
   u64 *zp0a = w->zp0, *zp0b = w->zp0 + n + 1, *zp1a = w->zp1, *zp1b = w->zp1 + n + 1;
   u64 *zi0a = w->zi0, *zi0b = w->zi0 + n + 1, *zi1a = w->zi1, *zi1b = w->zi1 + n + 1;
+  ProfScope* pso = new ProfScope(w, s, PF_OPENINGS, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 8));
   ext_powers(zp0a, zp0b, n + 1, zeta, ex(1, 0), s); ext_powers(zp1a, zp1b, n + 1, gzeta, ex(1, 0), s);
   ext_powers(zi0a, zi0b, n + 1, zinv, ex(1, 0), s); ext_powers(zi1a, zi1b, n + 1, gzinv, ex(1, 0), s);
   {
@@ -351,6 +392,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)nch * npp;
     open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, o, s);
   }
+  delete pso;
   HIP_TRY(hipMemcpyAsync(pin, w->openings, 16 * L.n_openings, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   mark();
@@ -363,17 +405,21 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   }
   // ---- 9: FRI
   const Ext fa = ch.challenge_ext();
+  ProfScope* psc = new ProfScope(w, s, PF_FRI_COMBINE, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 24));
   fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
               PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->comp0, w->comp1, s);
   fri_divide_combine(w->comp0, w->comp1, c->log_n, zp0a, zp0b, zp1a, zp1b, zi0a, zi0b, zi1a, zi1b, ex_pow(fa, nch), w->div_scratch, w->fri_coeffs[0], s);
+  delete psc;
   Ext fri_betas[MAX_FRI_LAYERS];
   for (int l = 0; l < c->nlayers; l++) {
     const int lg = c->fri_log_n[l]; const size_t nl = size_t(1) << lg, Nl = nl << c->rate;
+    ProfScope* psl = new ProfScope(w, s, PF_FRI_LAYERS, 8.0 * (2 * nl + 2 * Nl * 2 + 12 * (Nl >> c->arity[l])));
     lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s);
     const size_t leaves = Nl >> c->arity[l];
     merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
     merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
     size_t cap_off = merkle_total_digests(leaves, c->cap_h) - capn;
+    delete psl;
     HIP_TRY(hipMemcpyAsync(pin, w->fri_dig[l] + cap_off * 4, L.cap_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
@@ -401,7 +447,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s));
     u64 base = 0, span = 1ULL << 18;
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
-      pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s);
+      { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
       HIP_TRY(hipMemcpyAsync(pin, w->pow_result, 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       pow_witness = pin[0]; base += span; if (span < (1ULL << 26)) span <<= 1;
@@ -429,13 +475,14 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   }
   ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query;
   for (int q = 0; q < ga.nq; q++) ga.idx[q] = (u32)(ch.challenge() % N);
-  query_gather(ga, w->query_bytes, s);
+  { ProfScope ps(w, s, PF_GATHER, 2.0 * L.bytes_per_query * ga.nq); query_gather(ga, w->query_bytes, s); }
   HIP_TRY(hipMemcpyAsync(pin, w->query_bytes, L.bytes_per_query * ga.nq, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   memcpy(out + L.queries_off, pin, L.bytes_per_query * ga.nq);
   { u64 npi = d.num_public_inputs; memcpy(out + L.pis_off, &npi, 8); memcpy(out + L.pis_off + 8, pis, 8 * npi); }
   mark();
+  prof_flush(w);
   if (timing) {
     g_stage_n = nev - 1;
     for (int i = 0; i + 1 < nev; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); g_stage_ms[i] = ms; }
@@ -446,6 +493,17 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
 
 extern "C" {
 
+// Per-kernel-group timing for bench.py's roofline object (HIP events on the proving stream; off by default).
+void qpgpu_profile_enable(int on) { g_prof_on.store(on); }
+void qpgpu_profile_reset(void) { std::lock_guard<std::mutex> lk(g_prof_mu); for (auto& a : g_prof) a = ProfAcc(); }
+int qpgpu_profile_count(void) { return PF_COUNT; }
+const char* qpgpu_profile_name(int id) { return id >= 0 && id < PF_COUNT ? PROF_NAMES[id] : ""; }
+int qpgpu_profile_get(int id, uint64_t* launches, double* ms, double* alg_bytes) {
+  if (id < 0 || id >= PF_COUNT) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *launches = g_prof[id].launches; *ms = g_prof[id].ms; *alg_bytes = g_prof[id].bytes; return 0;
+}
+
 int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
                 const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len) {
   if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");
@@ -455,7 +513,7 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
   Workspace* w = nullptr; int rc = ws_acquire(c, &w); if (rc) return rc;
   hipStream_t s = (opts && opts->stream) ? (hipStream_t)opts->stream : w->stream;
   rc = prove_one(c, w, s, wires, public_inputs, opts, opts ? opts->salt_seed : 0, opts ? opts->salts : nullptr, out);
-  if (rc != 0) (void)hipStreamSynchronize(s);
+  if (rc != 0) { (void)hipStreamSynchronize(s); w->pev_used = 0; }
   ws_release(c, w);
   if (rc == 0 && out_len) *out_len = c->lay.total;
   return rc;
@@ -479,7 +537,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
       o.stream = nullptr;
       const u64* salts = (opts && opts->salts) ? opts->salts + i * 3 * 4 * c->N : nullptr;
       rc = prove_one(c, w, w->stream, wires[i], public_inputs[i], &o, o.salt_seed + i, salts, out + i * out_stride);
-      if (rc) { (void)hipStreamSynchronize(w->stream); std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
+      if (rc) { (void)hipStreamSynchronize(w->stream); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
       if (out_lens) out_lens[i] = c->lay.total;
     }
     ws_release(c, w);

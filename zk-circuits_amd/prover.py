@@ -1,0 +1,152 @@
+"""WormholeProver mirror (reference: /root/reference/wormhole/prover/src/lib.rs:74-237).
+
+Same shape as the reference wrapper: `WormholeProver.new(config)` builds the circuit (here: the synthetic
+wormhole-shaped circuit package, because plonky2's CircuitBuilder needs the absent Rust toolchain — SURVEY.md §8(d)) and
+uploads it to the GPU once; `commit(inputs)` fills the witness and may be called only once; `prove()` returns a
+`ProofWithPublicInputs` whose bytes are plonky2's `to_bytes()` layout.
+"""
+import ctypes
+import numpy as np
+from . import ffi
+
+P = 0xFFFFFFFF00000001
+
+
+class CircuitConfig:
+    """The two presets the reference uses (wormhole/tests/src/prover/prover_tests.rs:11, wormhole/prover/benches/prover.rs:12)."""
+
+    def __init__(self, zero_knowledge, preset):
+        self.zero_knowledge = zero_knowledge
+        self.preset = preset
+
+    @staticmethod
+    def standard_recursion_config():
+        return CircuitConfig(False, "A")
+
+    @staticmethod
+    def standard_recursion_zk_config():
+        return CircuitConfig(True, "B")
+
+    @staticmethod
+    def test_config(zero_knowledge=False):
+        return CircuitConfig(zero_knowledge, "TZ" if zero_knowledge else "T")
+
+
+class CircuitInputs:
+    """Stand-in for wormhole_circuit::inputs::CircuitInputs (wormhole/circuit/src/inputs.rs:23-55): a witness seed for
+    the synthetic generator, or an explicit full witness (wires [W][n], public_inputs [16])."""
+
+    def __init__(self, seed=None, wires=None, public_inputs=None):
+        if (seed is None) == (wires is None):
+            raise ValueError("give either a seed or an explicit witness")
+        self.seed, self.wires, self.public_inputs = seed, wires, public_inputs
+
+    @staticmethod
+    def test_inputs(index=0):
+        return CircuitInputs(seed=0x51570000 + index)
+
+
+class ProofWithPublicInputs:
+    def __init__(self, data, num_public_inputs):
+        self.data = data
+        k = num_public_inputs
+        self.public_inputs = list(np.frombuffer(data[len(data) - 8 * k:], dtype="<u8"))
+
+    def to_bytes(self):
+        return self.data
+
+    def __len__(self):
+        return len(self.data)
+
+
+class WormholeCircuitData:
+    """Resident circuit: synthetic package + qpgpu_circuit handle; shared by provers of the same config."""
+    _cache = {}
+
+    def __init__(self, config, device=0):
+        S = ffi.synth_lib()
+        L = ffi.lib()
+        self.config = config
+        params = ffi.SynthParams()
+        if S.qpsynth_preset(config.preset.encode(), ctypes.byref(params)) != 0:
+            raise ValueError(S.qpsynth_last_error().decode())
+        self._synth = ctypes.c_void_p()
+        if S.qpsynth_circuit_create(ctypes.byref(params), ctypes.byref(self._synth)) != 0:
+            raise ValueError(S.qpsynth_last_error().decode())
+        self.desc = S.qpsynth_circuit_desc(self._synth).contents
+        self.n = 1 << self.desc.degree_bits
+        self.num_wires = self.desc.num_wires
+        self.num_public_inputs = self.desc.num_public_inputs
+        self._ctx = ctypes.c_void_p()
+        ffi.check(L.qpgpu_ctx_create(device, ctypes.byref(self._ctx)))
+        self._circuit = ctypes.c_void_p()
+        ffi.check(L.qpgpu_circuit_create(self._ctx, ctypes.byref(self.desc), ctypes.byref(self._circuit)))
+        self.proof_size = L.qpgpu_proof_size(self._circuit)
+
+    @classmethod
+    def get(cls, config, device=0):
+        key = (config.preset, device)
+        if key not in cls._cache:
+            cls._cache[key] = cls(config, device)
+        return cls._cache[key]
+
+    def witness(self, seed):
+        wires = np.zeros((self.num_wires, self.n), dtype=np.uint64)
+        pis = np.zeros(self.num_public_inputs, dtype=np.uint64)
+        ffi.synth_lib().qpsynth_witness(self._synth, seed, wires.ctypes.data_as(ffi.u64p), pis.ctypes.data_as(ffi.u64p))
+        return wires, pis
+
+    def constants_sigmas_cap(self):
+        out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
+        ffi.check(ffi.lib().qpgpu_circuit_constants_sigmas_cap(self._circuit, out.ctypes.data_as(ffi.u64p)))
+        return out
+
+
+class WormholeProver:
+    def __init__(self, circuit_data):
+        self.circuit_data = circuit_data
+        self._targets = True          # Option<CircuitTargets>: taken by commit (lib.rs:210-212)
+        self._witness = None
+
+    @staticmethod
+    def new(config, device=0):
+        return WormholeProver(WormholeCircuitData.get(config, device))
+
+    @staticmethod
+    def default(device=0):
+        return WormholeProver.new(CircuitConfig.standard_recursion_zk_config(), device)
+
+    def commit(self, circuit_inputs):
+        if not self._targets:
+            raise RuntimeError("prover has already commited to inputs")
+        self._targets = False
+        cd = self.circuit_data
+        if circuit_inputs.wires is not None:
+            wires = np.ascontiguousarray(circuit_inputs.wires, dtype=np.uint64)
+            pis = np.ascontiguousarray(circuit_inputs.public_inputs, dtype=np.uint64)
+            if wires.shape != (cd.num_wires, cd.n) or pis.shape != (cd.num_public_inputs,):
+                raise ValueError("witness shape mismatch")
+            self._salt_seed = 0
+        else:
+            wires, pis = cd.witness(circuit_inputs.seed)
+            self._salt_seed = circuit_inputs.seed
+        self._witness = (wires, pis)
+        return self
+
+    def prove(self, pow_witness=None):
+        if self._witness is None:
+            raise RuntimeError("Failed to prove: prover has not commited to any inputs")
+        cd = self.circuit_data
+        wires, pis = self._witness
+        self._witness = None                     # prove(self) consumes the prover (lib.rs:233)
+        o = ffi.ProveOpts()
+        o.salt_seed = self._salt_seed
+        if pow_witness is not None:
+            o.have_pow_witness, o.pow_witness = 1, pow_witness
+        buf = ctypes.create_string_buffer(cd.proof_size)
+        n = ctypes.c_size_t()
+        rc = ffi.lib().qpgpu_prove(cd._circuit, wires.ctypes.data, pis.ctypes.data_as(ffi.u64p), len(pis), ctypes.byref(o),
+                                   buf, cd.proof_size, ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("Failed to prove: %s" % ffi.lib().qpgpu_last_error().decode())
+        return ProofWithPublicInputs(buf.raw[:n.value], cd.num_public_inputs)
