@@ -3,7 +3,7 @@
 // The batch combine is done in coefficient space like upstream (it reads n-length coefficient columns, 8x fewer bytes
 // than combining LDE values); the division by (X - z) is a suffix sum against precomputed powers of z.
 #include "kernels.h"
-#include "poseidon.h"
+#include "poseidon_dev.h"
 
 namespace qp {
 
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_pow_grind(Sponge12 sp, int pos, u64 bas
   for (int k = 0; k < 12; k++) st[k] = sp.s[k];
 #pragma unroll
   for (int k = 0; k < 8; k++) if (k == pos) st[k] = cand;
-  poseidon_permute(st);
+  poseidon_permute_dev(st);
   int lz = st[7] == 0 ? 64 : __clzll((long long)st[7]);
   if (lz >= bits) atomicMin((unsigned long long*)result, (unsigned long long)cand);
 }

@@ -2,7 +2,7 @@
 // {hash_or_noop, two_to_one} of qp-plonky2, behind wormhole/prover/src/lib.rs:233-237).
 // One permutation per lane, state in VGPRs; leaves stream column-major oracle values (coalesced across lanes).
 #include "kernels.h"
-#include "poseidon.h"
+#include "poseidon_dev.h"
 #include "salt.h"
 
 namespace qp {
@@ -21,7 +21,7 @@ __global__ void k_permute_batch(u64* states, size_t count) {
   u64 st[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) st[k] = states[i * 12 + k];
-  poseidon_permute(st);
+  poseidon_permute_dev(st);
 #pragma unroll
   for (int k = 0; k < 12; k++) states[i * 12 + k] = st[k];
 }
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
 #pragma unroll
         for (int k = 0; k < 8; k++) if (k < m) st[k] = cols[(size_t)(off + k) * col_stride + L];
       }
-      poseidon_permute(st);
+      poseidon_permute_dev(st);
     }
   }
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_leaves_fri(const u64* a, const u64* b, 
     for (int off = 0; off < width; off += 8) {      // width is a multiple of 8 for arity >= 4; arity 2 handled above
 #pragma unroll
       for (int k = 0; k < 4; k++) { st[2 * k] = pa[off / 2 + k]; st[2 * k + 1] = pb[off / 2 + k]; }
-      poseidon_permute(st);
+      poseidon_permute_dev(st);
     }
   }
 #pragma unroll
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(128) k_levels(u64* in_level, size_t in_count, 
       for (int k = 0; k < 8; k++) st[k] = sm[threadIdx.x * 8 + k];
 #pragma unroll
       for (int k = 8; k < 12; k++) st[k] = 0;
-      poseidon_permute(st);
+      poseidon_permute_dev(st);
     }
     __syncthreads();
     if (act) {

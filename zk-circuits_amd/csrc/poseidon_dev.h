@@ -1,0 +1,96 @@
+// Device-only Poseidon-Goldilocks permutation tuned for gfx950 VALU issue (profiles/r01_valu_issue_rates.txt: v_mad_u64_u32
+// issues at the same ~4.3 cycles as a 32-bit add-with-carry, so the design minimises instruction count, not multiplies).
+//  * state elements are "lazy" residues: any u64 congruent to the value (canonicalised once, at the end);
+//  * 64x64->128 products are four v_mad_u64_u32 chained through their 64-bit addends;
+//  * the MDS row sums accumulate the 32-bit halves separately with v_mad_u64_u32 (constants < 2^6, sums < 2^42) and the next
+//    round's constant rides in as the initial addend, so add-round-constant costs nothing after round 0;
+//  * one 128->64 reduction per product / per MDS row, using 2^64 = 2^32-1 and 2^96 = -1 (mod p).
+// Same function as poseidon.h (tests compare both with the oracle); reference semantics: SURVEY.md App. A.2.
+#pragma once
+#include "gl.h"
+#include "poseidon.h"
+
+namespace qp {
+
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+// lo + 2^64*hi  ->  lazy residue (any u64 congruent mod p)
+__device__ __forceinline__ u64 red128_lazy(u64 lo, u64 hi) {
+  const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+  u64 t0 = lo - h1;
+  const u32 bm = lo < (u64)h1 ? 0xFFFFFFFFu : 0u;       // wrapped by 2^64: owe -(2^32-1)
+  u64 u = (u64)h0 * 0xFFFFFFFFu;                         // h0 * (2^32-1) < 2^64
+  u64 t2 = t0 + u;
+  const u32 cm = t2 < u ? 0xFFFFFFFFu : 0u;             // wrapped: owe +(2^32-1)
+  // t2 + cm - bm (as 64-bit quantities 0 or 2^32-1); cannot wrap again
+  return t2 + (u64)cm - (u64)bm;
+}
+__device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p0 = mad32(a0, b0, 0);
+  u64 p1 = mad32(a0, b1, p0 >> 32);
+  u64 p2 = mad32(a1, b0, (u32)p1);
+  u64 hi = mad32(a1, b1, (p1 >> 32) + (p2 >> 32));
+  u64 lo = (p2 << 32) | (u32)p0;
+  return red128_lazy(lo, hi);
+}
+__device__ __forceinline__ u64 sbox7_lazy(u64 x) {
+  u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x2, x);
+  return mul_lazy(x3, x4);
+}
+__device__ __forceinline__ u64 canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+// x + c for lazy x and canonical c
+__device__ __forceinline__ u64 add_lazy_canon(u64 x, u64 c) {
+  u64 s = x + c; if (s < c) s += GL_EPS; return s;
+}
+
+// MDS with the next round's constants folded in: st[r] = sum_i C[i]*st[(i+r)%12] + 8*st[0]*[r==0] + rc[r]   (lazy)
+__device__ __forceinline__ void mds_rc_lazy(u64 st[12], const u64* __restrict__ rc) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { lo[i] = (u32)st[i]; hi[i] = (u32)(st[i] >> 32); }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 c = rc ? rc[r] : 0;
+    u64 sl = (u32)c, sh = c >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { sl = mad32(lo[(i + r) % 12], C[i], sl); sh = mad32(hi[(i + r) % 12], C[i], sh); }
+    if (r == 0) { sl = mad32(lo[0], 8, sl); sh = mad32(hi[0], 8, sh); }
+    // value = sl + 2^32*sh, sl, sh < 2^43:  2^32*sh = (sh_lo << 32) + sh_hi*2^64 == (sh_lo << 32) + sh_hi*(2^32-1)
+    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
+    u64 add = (u64)(u32)sh << 32;
+    u64 v = t + add;
+    if (v < add) v += GL_EPS;
+    st[r] = v;
+  }
+}
+
+// Full permutation on lazy/canonical input; output canonical.
+__device__ __forceinline__ void poseidon_permute_dev(u64 st[12]) {
+  const u64* rc = POSEIDON_RC_DEV;
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], rc[i]);
+  int r = 0;
+  for (; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+    mds_rc_lazy(st, rc + 12 * (r + 1));
+  }
+  for (; r < 26; r++) {
+    st[0] = sbox7_lazy(st[0]);
+    mds_rc_lazy(st, rc + 12 * (r + 1));
+  }
+  for (; r < 29; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+    mds_rc_lazy(st, rc + 12 * (r + 1));
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+  mds_rc_lazy(st, nullptr);
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
+}
+
+} // namespace qp
