@@ -78,46 +78,61 @@ __global__ void __launch_bounds__(256) k_leaves_fri(const u64* a, const u64* b, 
 #pragma unroll
   for (int k = 0; k < 4; k++) digests[L * 4 + k] = st[k];
 }
+// cooperative form: 16 lanes per leaf (layers have few leaves, each a short sponge)
+__global__ void __launch_bounds__(64) k_leaves_fri_coop(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests) {
+  __shared__ u64 xch[4][12];
+  const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
+  const size_t L = (size_t)blockIdx.x * 4 + g, LL = L < num_leaves ? L : num_leaves - 1;
+  CoopCtx cx; coop_init(cx, i);
+  const int width = 2 << arity_bits;
+  const u64* pa = a + (LL << arity_bits); const u64* pb = b + (LL << arity_bits);
+  u64 x = 0;
+  if (width <= 4) { if (i < width) x = (i & 1) ? pb[i >> 1] : pa[i >> 1]; }
+  else {
+    for (int off = 0; off < width; off += 8) {
+      if (i < 8) { int f = off + i; x = (f & 1) ? pb[f >> 1] : pa[f >> 1]; }
+      x = coop_permute(x, i, cx, xch[g]);
+    }
+  }
+  if (L < num_leaves && i < 4) digests[L * 4 + i] = x;
+}
 void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s) {
+  if (num_leaves <= 16384) { hipLaunchKernelGGL(k_leaves_fri_coop, dim3((unsigned)((num_leaves + 3) / 4)), dim3(64), 0, s, a, b, arity_bits, num_leaves, digests); return; }
   hipLaunchKernelGGL(k_leaves_fri, dim3((unsigned)((num_leaves + 255) / 256)), dim3(256), 0, s, a, b, arity_bits, num_leaves, digests);
 }
 
-// One block reduces 2^r consecutive nodes of a level by up to r levels, writing every intermediate level.
-static constexpr int LV_R = 8;   // 256 nodes in, 128 threads active at the first step
-__global__ void __launch_bounds__(128) k_levels(u64* in_level, size_t in_count, u64* out_levels, int steps) {
-  __shared__ u64 sm[256 * 4];
-  const size_t base = (size_t)blockIdx.x << LV_R;
-  for (unsigned e = threadIdx.x; e < 256 * 4; e += 128) { size_t g = base * 4 + e; sm[e] = g < in_count * 4 ? in_level[g] : 0; }
-  __syncthreads();
-  size_t lvl_count = in_count; u64* out = out_levels; unsigned width = 256;
-  for (int st_i = 0; st_i < steps; st_i++) {
-    width >>= 1; lvl_count >>= 1;
-    u64 st[12]; bool act = threadIdx.x < width && ((base >> (st_i + 1)) + threadIdx.x) < lvl_count;
-    if (act) {
+// ---- upper levels. A level with many parents runs one permutation per lane; below COOP_MAX_PARENTS the stage is
+// latency-bound (one per-lane permutation is ~26k dependent-issue instructions), so 16 lanes share each permutation.
+__global__ void __launch_bounds__(256) k_level_lane(const u64* in, u64* out, size_t parents) {
+  size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= parents) return;
+  u64 st[12];
 #pragma unroll
-      for (int k = 0; k < 8; k++) st[k] = sm[threadIdx.x * 8 + k];
+  for (int k = 0; k < 8; k++) st[k] = in[p * 8 + k];
 #pragma unroll
-      for (int k = 8; k < 12; k++) st[k] = 0;
-      poseidon_permute_dev(st);
-    }
-    __syncthreads();
-    if (act) {
-      size_t node = (base >> (st_i + 1)) + threadIdx.x;
+  for (int k = 8; k < 12; k++) st[k] = 0;
+  poseidon_permute_dev(st);
 #pragma unroll
-      for (int k = 0; k < 4; k++) { sm[threadIdx.x * 4 + k] = st[k]; out[node * 4 + k] = st[k]; }
-    }
-    __syncthreads();
-    out += lvl_count * 4;
-  }
+  for (int k = 0; k < 4; k++) out[p * 4 + k] = st[k];
 }
+__global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size_t parents) {
+  __shared__ u64 xch[4][12];
+  const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
+  const size_t p = (size_t)blockIdx.x * 4 + g;
+  CoopCtx cx; coop_init(cx, i);
+  const size_t pp = p < parents ? p : parents - 1;
+  u64 x = i < 8 ? in[pp * 8 + i] : 0;
+  x = coop_permute(x, i, cx, xch[g]);
+  if (p < parents && i < 4) out[p * 4 + i] = x;
+}
+static constexpr size_t COOP_MAX_PARENTS = 16384;
 void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s) {
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
   while (cnt > cap) {
-    int steps = 0; { size_t c = cnt; while (c > cap && steps < LV_R) { c >>= 1; steps++; } }
-    unsigned blocks = (unsigned)((cnt + 255) >> LV_R);
-    u64* out = cur + cnt * 4;
-    hipLaunchKernelGGL(k_levels, dim3(blocks), dim3(128), 0, s, cur, cnt, out, steps);
-    for (int i = 0; i < steps; i++) { cur += cnt * 4; cnt >>= 1; }
+    size_t parents = cnt >> 1; u64* out = cur + cnt * 4;
+    if (parents > COOP_MAX_PARENTS) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
+    else hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, cur, out, parents);
+    cur = out; cnt = parents;
   }
 }
 

@@ -93,4 +93,44 @@ __device__ __forceinline__ void poseidon_permute_dev(u64 st[12]) {
   for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative permutation: 16 consecutive lanes hold one state (lane i < 12 holds element i; lanes 12..15 idle), so a
+// 64-lane wave runs 4 permutations with ~1/12 of the per-lane instruction stream each. Throughput is ~3x worse than the
+// one-permutation-per-lane form, latency ~6x better: used where a stage has too few independent permutations to fill the chip
+// (upper Merkle levels, FRI layer leaves). `xch` is this group's 12-u64 exchange slot in LDS; the caller's block is ONE wave
+// (64 threads), so the barriers below are wave-local.
+struct CoopCtx {
+  u64 rc[30];     // this lane's round constants
+  u32 m[12];      // this lane's MDS row: m[j] multiplies element j
+};
+__device__ __forceinline__ void coop_init(CoopCtx& cx, int i) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  const int ii = i < 12 ? i : 0;
+#pragma unroll
+  for (int r = 0; r < 30; r++) cx.rc[r] = POSEIDON_RC_DEV[12 * r + ii];
+#pragma unroll
+  for (int j = 0; j < 12; j++) cx.m[j] = C[(j - ii + 12) % 12] + ((ii == 0 && j == 0) ? 8u : 0u);
+}
+// x: this lane's element (canonical or lazy in; canonical out). All 64 lanes of the wave must call this.
+__device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64* xch) {
+  x = add_lazy_canon(x, cx.rc[0]);
+#pragma unroll
+  for (int r = 0; r < 30; r++) {
+    const bool full = r < 4 || r >= 26;
+    if (full || i == 0) x = sbox7_lazy(x);
+    if (i < 12) xch[i] = x;
+    __syncthreads();
+    u64 c = r + 1 < 30 ? cx.rc[r + 1] : 0;
+    u64 sl = (u32)c, sh = c >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { u64 v = xch[j]; sl = mad32((u32)v, cx.m[j], sl); sh = mad32((u32)(v >> 32), cx.m[j], sh); }
+    __syncthreads();
+    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
+    u64 add = (u64)(u32)sh << 32;
+    x = t + add;
+    if (x < add) x += GL_EPS;
+  }
+  return canon(x);
+}
+
 } // namespace qp

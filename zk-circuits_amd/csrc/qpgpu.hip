@@ -445,7 +445,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const int pos = ch.n_in;
     u64 none = ~0ULL; pow_witness = none;
     HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s));
-    u64 base = 0, span = 1ULL << 18;
+    u64 base = 0, span = 1ULL << 17;
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
       HIP_TRY(hipMemcpyAsync(pin, w->pow_result, 8, hipMemcpyDeviceToHost, s));
