@@ -7,26 +7,48 @@
 
 namespace qp {
 
-// ---- compose: comp0[i] = sum_j alpha^j f_j[i] over 4 groups (Horner from the last polynomial), comp1 from the first nch of g2
-__global__ void __launch_bounds__(256) k_fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, size_t n,
-                                                     Ext alpha, u64* comp0, u64* comp1) {
+// ---- compose: comp0[i] = sum_j alpha^j f_j[i] over the 4 oracle groups, comp1 from the first nch polynomials of g2.
+// The polynomial list is cut into FRI_COMPOSE_GROUPS runs so the Horner chains are short and the grid fills the chip;
+// each step acc*alpha + f is two 2-term dot products with a single reduction each.
+struct ComposeArgs { PolyGroup g[4]; int total; int per_group; Ext alpha; Ext alpha_run; /* alpha^per_group */ };
+__device__ __forceinline__ u64 compose_coeff(const ComposeArgs& a, int j, size_t i) {
+  int k = j;
+#pragma unroll
+  for (int gi = 0; gi < 4; gi++) { if (k < a.g[gi].count) return a.g[gi].base[(size_t)k * a.g[gi].stride + i]; k -= a.g[gi].count; }
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_fri_compose_partial(ComposeArgs a, size_t n, u64* partial) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int grp = blockIdx.y, j0 = grp * a.per_group, j1 = j0 + a.per_group < a.total ? j0 + a.per_group : a.total;
+  const u64 al0 = a.alpha.a, al1 = a.alpha.b, al1x7 = gl_mul7(a.alpha.b);
+  u64 x0 = 0, x1 = 0;
+  for (int j = j1 - 1; j >= j0; j--) {
+    u64 f = compose_coeff(a, j, i);
+    u64 n0 = dot2_lazy(x0, al0, x1, al1x7);      // (x0 + x1 X)(al0 + al1 X) with X^2 = 7
+    u64 n1 = dot2_lazy(x0, al1, x1, al0);
+    x0 = add_lazy_canon(n0, f); x1 = n1;
+  }
+  partial[((size_t)grp * 2) * n + i] = canon(x0); partial[((size_t)grp * 2 + 1) * n + i] = canon(x1);
+}
+__global__ void __launch_bounds__(256) k_fri_compose_finish(const u64* partial, size_t n, int groups, Ext alpha_run, PolyGroup g2, int nch, Ext alpha,
+                                                            u64* comp0, u64* comp1) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ext acc = ex(0, 0);
-  const PolyGroup* gs[4] = {&g0, &g1, &g2, &g3};
-#pragma unroll
-  for (int gi = 3; gi >= 0; gi--) {
-    const PolyGroup& g = *gs[gi];
-    for (int j = g.count - 1; j >= 0; j--) acc = ex_add_base(ex_mul(acc, alpha), g.base[(size_t)j * g.stride + i]);
-  }
+  for (int g = groups - 1; g >= 0; g--) acc = ex_add(ex_mul(acc, alpha_run), ex(partial[((size_t)g * 2) * n + i], partial[((size_t)g * 2 + 1) * n + i]));
   comp0[i] = acc.a; comp0[n + i] = acc.b;
   Ext a1 = ex(0, 0);
   for (int j = nch - 1; j >= 0; j--) a1 = ex_add_base(ex_mul(a1, alpha), g2.base[(size_t)j * g2.stride + i]);
   comp1[i] = a1.a; comp1[n + i] = a1.b;
 }
-void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* comp0, u64* comp1, hipStream_t s) {
+void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* partial, u64* comp0, u64* comp1, hipStream_t s) {
   size_t n = size_t(1) << log_n;
-  hipLaunchKernelGGL(k_fri_compose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, g3, nch, n, alpha, comp0, comp1);
+  ComposeArgs a; a.g[0] = g0; a.g[1] = g1; a.g[2] = g2; a.g[3] = g3; a.total = g0.count + g1.count + g2.count + g3.count;
+  a.per_group = (a.total + FRI_COMPOSE_GROUPS - 1) / FRI_COMPOSE_GROUPS; a.alpha = alpha; a.alpha_run = ex_pow(alpha, (u64)a.per_group);
+  dim3 grid((unsigned)((n + 255) / 256), FRI_COMPOSE_GROUPS);
+  hipLaunchKernelGGL(k_fri_compose_partial, grid, dim3(256), 0, s, a, n, partial);
+  hipLaunchKernelGGL(k_fri_compose_finish, dim3(grid.x), dim3(256), 0, s, partial, n, FRI_COMPOSE_GROUPS, a.alpha_run, g2, nch, alpha, comp0, comp1);
 }
 
 // ---- divide: t_i = comp[i] * z^i ; S_k = sum_{i>k} t_i ; Q[k] = S_k * z^-(k+1)

@@ -23,13 +23,14 @@ static constexpr u64 GL_EPS = 0xFFFFFFFFULL;
 static constexpr u64 GL_GEN = 14293326489335486720ULL;     // multiplicative generator = LDE coset shift
 static constexpr u64 GL_POW2_GEN = 7277203076849721926ULL;  // generator of the 2^32 subgroup
 
+// Branch-free (select) forms: on the host the inputs are effectively random, so branches would mispredict.
 QP_HD u64 gl_add(u64 a, u64 b) {
   u64 s = a + b;
-  if (s < a) s += GL_EPS;            // wrapped past 2^64 == 2^32 - 1 (mod p); result is canonical
-  else if (s >= GL_P) s -= GL_P;
-  return s;
+  u64 wrapped = 0 - (u64)(s < a);                 // all ones if the 64-bit add wrapped (2^64 == 2^32 - 1 mod p)
+  u64 over = 0 - (u64)(s >= GL_P);                // only meaningful when not wrapped
+  return s + (wrapped & GL_EPS) - (~wrapped & over & GL_P);   // canonical for canonical inputs
 }
-QP_HD u64 gl_sub(u64 a, u64 b) { u64 d = a - b; if (a < b) d += GL_P; return d; }
+QP_HD u64 gl_sub(u64 a, u64 b) { u64 d = a - b; return d + ((0 - (u64)(a < b)) & GL_P); }
 QP_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
 QP_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
@@ -42,10 +43,10 @@ QP_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
 // x = lo + 2^64 * hi  ->  canonical residue.  2^64 == 2^32 - 1, 2^96 == -1 (mod p).
 QP_HD u64 gl_reduce128(u64 lo, u64 hi) {
   u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-  u64 t0 = lo - hi_hi; if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t0 = lo - hi_hi; t0 -= (0 - (u64)(lo < hi_hi)) & GL_EPS;
   u64 t1 = (hi_lo << 32) - hi_lo;
-  u64 t2 = t0 + t1; if (t2 < t1) t2 += GL_EPS;
-  if (t2 >= GL_P) t2 -= GL_P;
+  u64 t2 = t0 + t1; t2 += (0 - (u64)(t2 < t1)) & GL_EPS;
+  t2 -= (0 - (u64)(t2 >= GL_P)) & GL_P;
   return t2;
 }
 QP_HD u64 gl_mul(u64 a, u64 b) { u64 lo, hi; mul64wide(a, b, lo, hi); return gl_reduce128(lo, hi); }

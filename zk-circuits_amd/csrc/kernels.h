@@ -80,13 +80,20 @@ void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde
 
 // out_a[i], out_b[i] = scale * base^i in F_{p^2}, i < count
 void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipStream_t s);
+// Four power tables in one launch: out[t][i] = base_t^i (i < count), given pw[t][k] = base_t^(2^k).
+struct ExtPowArgs { u64* out_a[4]; u64* out_b[4]; Ext pw[4][28]; size_t count; int nbits; };
+void ext_powers4(const ExtPowArgs& a, hipStream_t s);
 // Openings (row a9): out[p] = sum_i polys[p][i] * zp[i]  for p < count; out as interleaved (a,b) pairs.
-void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext, hipStream_t s);
+// partial: scratch of 2*count*open_chunks(log_n) u64.
+int open_chunks(int log_n);
+void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* partial, u64* out_ext, hipStream_t s);
 
 // ---------------- FRI (fri.hip) ----------------
 struct PolyGroup { const u64* base; size_t stride; int count; };
 // comp0 = sum_j alpha^j f_j over the 4 oracle coefficient groups in order; comp1 = sum_j alpha^j zs_j (j < nch). Outputs [2][n] each (a then b).
-void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* comp0, u64* comp1, hipStream_t s);
+// partial: scratch of FRI_COMPOSE_GROUPS * 2 * n u64.
+static constexpr int FRI_COMPOSE_GROUPS = 8;
+void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* partial, u64* comp0, u64* comp1, hipStream_t s);
 // final[k] = alpha^nch * Q0[k] + Q1[k], Q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b); tables: zp_b = z_b^i, zi_b = z_b^{-i} (i <= n).
 // scratch: 4*n u64. final: [2][n].
 void fri_divide_combine(const u64* comp0, const u64* comp1, int log_n, const u64* zp0_a, const u64* zp0_b, const u64* zp1_a,

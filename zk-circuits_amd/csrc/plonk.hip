@@ -4,6 +4,7 @@
 // All oracles are column-major ([column][row]) so every per-row/per-point kernel reads coalesced.
 #include "kernels.h"
 #include "poseidon.h"
+#include "poseidon_dev.h"
 #include "../../include/qpgpu.h"
 
 namespace qp {
@@ -250,6 +251,18 @@ void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde
 }
 
 // ------------------------------------------------------------------ openings
+// Power tables: out[t][i] = base_t^i via the binary expansion of i against host-supplied base_t^(2^k).
+__global__ void __launch_bounds__(256) k_ext_powers4(ExtPowArgs a) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= a.count) return;
+  const int t = blockIdx.y;
+  Ext r = ex(1, 0);
+  for (int k = 0; k < a.nbits; k++) if ((i >> k) & 1) r = ex_mul(r, a.pw[t][k]);
+  a.out_a[t][i] = r.a; a.out_b[t][i] = r.b;
+}
+void ext_powers4(const ExtPowArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_ext_powers4, dim3((unsigned)((a.count + 255) / 256), 4), dim3(256), 0, s, a);
+}
 __global__ void k_ext_powers(u64* oa, u64* ob, size_t count, Ext base, Ext scale) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -260,23 +273,34 @@ void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipSt
   hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out_a, out_b, count, base, scale);
 }
 
-__global__ void __launch_bounds__(256) k_open(const u64* polys, size_t stride, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext) {
+// partial[p][chunk] = sum over the chunk of polys[p][i] * zp[i]; products accumulate in 192 bits, one reduction per thread.
+__global__ void __launch_bounds__(256) k_open_partial(const u64* polys, size_t stride, size_t n, int chunks, const u64* zp_a, const u64* zp_b, u64* partial) {
   __shared__ u64 sa[256], sb[256];
-  const size_t n = size_t(1) << log_n;
   const u64* p = polys + (size_t)blockIdx.x * stride;
-  u64 a = 0, b = 0;
-  for (size_t i = threadIdx.x; i < n; i += 256) { u64 c = p[i]; a = gl_add(a, gl_mul(c, zp_a[i])); b = gl_add(b, gl_mul(c, zp_b[i])); }
-  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  const size_t per = n / chunks, lo = (size_t)blockIdx.y * per, hi = lo + per;
+  Acc192 aa{0, 0, 0}, ab{0, 0, 0};
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) { u64 c = p[i]; acc_mul(aa, c, zp_a[i]); acc_mul(ab, c, zp_b[i]); }
+  sa[threadIdx.x] = acc_reduce(aa); sb[threadIdx.x] = acc_reduce(ab);
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (threadIdx.x < off) { sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + off]); sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + off]); }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out_ext[2 * (size_t)blockIdx.x] = sa[0]; out_ext[2 * (size_t)blockIdx.x + 1] = sb[0]; }
+  if (threadIdx.x == 0) { size_t o = ((size_t)blockIdx.x * chunks + blockIdx.y) * 2; partial[o] = sa[0]; partial[o + 1] = sb[0]; }
 }
-void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* out_ext, hipStream_t s) {
+__global__ void k_open_finish(const u64* partial, int count, int chunks, u64* out_ext) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= count) return;
+  u64 a = 0, b = 0;
+  for (int c = 0; c < chunks; c++) { a = gl_add(a, partial[((size_t)p * chunks + c) * 2]); b = gl_add(b, partial[((size_t)p * chunks + c) * 2 + 1]); }
+  out_ext[2 * (size_t)p] = a; out_ext[2 * (size_t)p + 1] = b;
+}
+int open_chunks(int log_n) { int c = log_n - 12; if (c < 0) c = 0; if (c > 6) c = 6; return 1 << c; }
+void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* partial, u64* out_ext, hipStream_t s) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_open, dim3((unsigned)count), dim3(256), 0, s, polys, stride, log_n, zp_a, zp_b, out_ext);
+  const int chunks = open_chunks(log_n);
+  hipLaunchKernelGGL(k_open_partial, dim3((unsigned)count, (unsigned)chunks), dim3(256), 0, s, polys, stride, size_t(1) << log_n, chunks, zp_a, zp_b, partial);
+  hipLaunchKernelGGL(k_open_finish, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, partial, count, chunks, out_ext);
 }
 
 } // namespace qp

@@ -26,6 +26,23 @@ QP_HD u64 sbox7(u64 x) { u64 x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2)
 // out[r] = sum_i st[(i+r)%12]*CIRC[i] + st[r]*DIAG[r], CIRC = {17,15,41,16,2,28,13,13,39,18,34,20}, DIAG = {8,0,...}.
 // The 32-bit halves are accumulated separately (sums < 2^41) and recombined into one 128-bit reduction.
 QP_HD void mds_layer(u64 st[12]) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // host (transcript, witness synthesis): 32-bit halves accumulated in u64 lanes (vectorisable), one reduction per row
+  static const u64 CC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 lo2[24], hi2[24];
+  for (int i = 0; i < 12; i++) { lo2[i] = lo2[i + 12] = st[i] & GL_EPS; hi2[i] = hi2[i + 12] = st[i] >> 32; }
+  u64 sl[12], sh[12];
+  for (int r = 0; r < 12; r++) { sl[r] = 0; sh[r] = 0; }
+  for (int i = 0; i < 12; i++)
+    for (int r = 0; r < 12; r++) { sl[r] += lo2[r + i] * CC[i]; sh[r] += hi2[r + i] * CC[i]; }
+  sl[0] += lo2[0] * 8; sh[0] += hi2[0] * 8;
+  for (int r = 0; r < 12; r++) {
+    u64 l = sl[r] + (sh[r] << 32);
+    u64 h = (sh[r] >> 32) + (l < sl[r] ? 1 : 0);
+    st[r] = gl_reduce128(l, h);
+  }
+  return;
+#endif
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u64 lo[12], hi[12];
 #pragma unroll

@@ -34,6 +34,44 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
   u64 lo = (p2 << 32) | (u32)p0;
   return red128_lazy(lo, hi);
 }
+// 128-bit product a*b -> (lo, hi)
+__device__ __forceinline__ void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p0 = mad32(a0, b0, 0);
+  u64 p1 = mad32(a0, b1, p0 >> 32);
+  u64 p2 = mad32(a1, b0, (u32)p1);
+  hi = mad32(a1, b1, (p1 >> 32) + (p2 >> 32));
+  lo = (p2 << 32) | (u32)p0;
+}
+// a0*b0 + a1*b1 (two 128-bit products, one reduction); result lazy. 2^128 == -2^32 (mod p).
+__device__ __forceinline__ u64 dot2_lazy(u64 a0, u64 b0, u64 a1, u64 b1) {
+  u64 l0, h0, l1, h1; mul_wide(a0, b0, l0, h0); mul_wide(a1, b1, l1, h1);
+  u64 lo = l0 + l1; u64 c0 = lo < l0;
+  u64 hi = h0 + h1; u64 c1 = hi < h0;
+  hi += c0; c1 += (hi < c0);
+  u64 r = red128_lazy(lo, hi);
+  // subtract c1 * 2^32 (c1 in {0,1}); r is lazy, so guard the borrow with +p
+  u64 sub = c1 << 32;
+  u64 d = r - sub; if (r < sub) d += GL_P;     // r + p - sub, cannot wrap twice since sub <= 2^32
+  return d;
+}
+// 192-bit accumulator for sums of 128-bit products (up to 2^32 terms)
+struct Acc192 { u64 lo, hi; u32 top; };
+__device__ __forceinline__ void acc_mul(Acc192& a, u64 x, u64 y) {
+  u64 l, h; mul_wide(x, y, l, h);
+  a.lo += l; u64 c = a.lo < l;
+  a.hi += h; u32 c2 = a.hi < h;
+  a.hi += c; c2 += (a.hi < c);
+  a.top += c2;
+}
+// canonical value of the accumulator: lo + 2^64 hi + 2^128 top, with 2^128 == -2^32
+__device__ __forceinline__ u64 acc_reduce(const Acc192& a) {
+  u64 r = red128_lazy(a.lo, a.hi);
+  r = r >= GL_P ? r - GL_P : r;
+  u64 t = gl_mul((u64)a.top, 1ULL << 32);
+  return gl_sub(r, t);
+}
+
 __device__ __forceinline__ u64 sbox7_lazy(u64 x) {
   u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x2, x);
   return mul_lazy(x3, x4);

@@ -60,7 +60,7 @@ struct Workspace {
   hipEvent_t pev[PROF_EVENTS]; int pev_made = 0, pev_used = 0; int pev_id[PROF_EVENTS / 2]; double pev_bytes[PROF_EVENTS / 2];
   DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
-  u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *comp0, *comp1, *div_scratch, *pow_result;
+  u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
   u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
   uint8_t* query_bytes;
 };
@@ -118,6 +118,8 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   w->alpha_pows = a.take((size_t)c->nch * 256);
   w->zp0 = a.take(2 * (n + 1)); w->zp1 = a.take(2 * (n + 1)); w->zi0 = a.take(2 * (n + 1)); w->zi1 = a.take(2 * (n + 1));
   w->openings = a.take(2 * c->lay.n_openings);
+  w->open_partial = a.take(2 * (size_t)(c->S + c->W) * open_chunks(c->log_n));
+  w->compose_partial = a.take((size_t)FRI_COMPOSE_GROUPS * 2 * n);
   w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n); w->pow_result = a.take(4);
   for (int l = 0; l <= c->nlayers; l++) w->fri_coeffs[l] = a.take((size_t)2 << c->fri_log_n[l]);
   for (int l = 0; l < c->nlayers; l++) {
@@ -381,16 +383,21 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   u64 *zp0a = w->zp0, *zp0b = w->zp0 + n + 1, *zp1a = w->zp1, *zp1b = w->zp1 + n + 1;
   u64 *zi0a = w->zi0, *zi0b = w->zi0 + n + 1, *zi1a = w->zi1, *zi1b = w->zi1 + n + 1;
   ProfScope* pso = new ProfScope(w, s, PF_OPENINGS, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 8));
-  ext_powers(zp0a, zp0b, n + 1, zeta, ex(1, 0), s); ext_powers(zp1a, zp1b, n + 1, gzeta, ex(1, 0), s);
-  ext_powers(zi0a, zi0b, n + 1, zinv, ex(1, 0), s); ext_powers(zi1a, zi1b, n + 1, gzinv, ex(1, 0), s);
+  {
+    ExtPowArgs pa; pa.count = n + 1; pa.nbits = c->log_n + 1;
+    pa.out_a[0] = zp0a; pa.out_b[0] = zp0b; pa.out_a[1] = zp1a; pa.out_b[1] = zp1b; pa.out_a[2] = zi0a; pa.out_b[2] = zi0b; pa.out_a[3] = zi1a; pa.out_b[3] = zi1b;
+    const Ext bases[4] = {zeta, gzeta, zinv, gzinv};
+    for (int t = 0; t < 4; t++) { Ext x = bases[t]; for (int k = 0; k < pa.nbits; k++) { pa.pw[t][k] = x; x = ex_mul(x, x); } }
+    ext_powers4(pa, s);
+  }
   {
     u64* o = w->openings;   // proof order: constants|sigmas (S), wires (W), zs (nch), zs_next (nch), pp (nch*npp), quotient (Q)
-    open_polys(c->d_cs_coeffs, n, c->S, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)c->S;
-    open_polys(w->wires_coeffs, n, c->W, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)c->W;
-    open_polys(w->zs_coeffs, n, nch, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)nch;
-    open_polys(w->zs_coeffs, n, nch, c->log_n, zp1a, zp1b, o, s); o += 2 * (size_t)nch;
-    open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, o, s); o += 2 * (size_t)nch * npp;
-    open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, o, s);
+    open_polys(c->d_cs_coeffs, n, c->S, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->S;
+    open_polys(w->wires_coeffs, n, c->W, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->W;
+    open_polys(w->zs_coeffs, n, nch, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)nch;
+    open_polys(w->zs_coeffs, n, nch, c->log_n, zp1a, zp1b, w->open_partial, o, s); o += 2 * (size_t)nch;
+    open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)nch * npp;
+    open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, w->open_partial, o, s);
   }
   delete pso;
   HIP_TRY(hipMemcpyAsync(pin, w->openings, 16 * L.n_openings, hipMemcpyDeviceToHost, s));
@@ -407,7 +414,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const Ext fa = ch.challenge_ext();
   ProfScope* psc = new ProfScope(w, s, PF_FRI_COMBINE, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 24));
   fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
-              PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->comp0, w->comp1, s);
+              PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->compose_partial, w->comp0, w->comp1, s);
   fri_divide_combine(w->comp0, w->comp1, c->log_n, zp0a, zp0b, zp1a, zp1b, zi0a, zi0b, zi1a, zi1b, ex_pow(fa, nch), w->div_scratch, w->fri_coeffs[0], s);
   delete psc;
   Ext fri_betas[MAX_FRI_LAYERS];
