@@ -105,6 +105,27 @@ void* orc_circuit_create(int degree_bits, int num_wires, int num_routed, int num
     return oc;
   } catch (std::exception& e) { fail(e.what()); return nullptr; }
 }
+// Verifier-only handle: no preprocessing; the constants/sigmas cap is supplied (e.g. from the prover under test).
+// Used for size-independent acceptance checks at sizes where the CPU preprocessing would take minutes.
+void* orc_verifier_create(int degree_bits, int num_wires, int num_routed, int num_constants, int num_challenges, int qdf,
+                          int num_partial_products, int num_public_inputs, int num_gate_constraints, int zk,
+                          int rate_bits, int cap_height, int num_queries, int pow_bits, int n_layers, const uint32_t* arity_bits,
+                          int n_gates, const uint32_t* gate_tags, const u64* gate_params, const uint32_t* selector_indices,
+                          int n_groups, const uint32_t* group_ranges, const u64* k_is, const u64* cap, const u64* digest) {
+  auto* oc = new OrcCircuit(); Common& c = oc->common;
+  c.num_wires = num_wires; c.num_routed = num_routed; c.cfg_num_constants = 2; c.security_bits = 100; c.num_challenges = num_challenges;
+  c.max_qdf = qdf; c.use_base_arith = true; c.zk = zk; c.rate_bits = rate_bits; c.cap_height = cap_height; c.num_queries = num_queries;
+  c.pow_bits = pow_bits; for (int i = 0; i < n_layers; i++) c.arity_bits.push_back((int)arity_bits[i]);
+  c.degree_bits = degree_bits; c.hiding = zk;
+  for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(Gate{(int)gate_tags[i], gate_params[i]}); }
+  for (int i = 0; i < n_groups; i++) c.groups.push_back({(int)group_ranges[2 * i], (int)group_ranges[2 * i + 1]});
+  c.qdf = qdf; c.num_gate_constraints = num_gate_constraints; c.num_constants = num_constants; c.num_public_inputs = num_public_inputs;
+  c.k_is.assign(k_is, k_is + num_routed); c.num_partial_products = num_partial_products;
+  memcpy(oc->digest.data(), digest, 32);
+  oc->pre.tree.levels.emplace_back();
+  for (int i = 0; i < (1 << cap_height); i++) { Hash h; memcpy(h.data(), cap + 4 * i, 32); oc->pre.tree.levels.back().push_back(h); }
+  return oc;
+}
 void orc_circuit_destroy(void* h) { delete (OrcCircuit*)h; }
 void orc_circuit_cap(void* h, u64* out) { auto* oc = (OrcCircuit*)h; size_t k = 0; for (auto& hh : oc->pre.tree.cap()) { memcpy(out + 4 * k, hh.data(), 32); k++; } }
 

@@ -64,6 +64,8 @@ def oracle():
         L.orc_proof_roundtrip.restype = ctypes.c_long
         L.orc_circuit_create.restype = ctypes.c_void_p
         L.orc_circuit_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p, ctypes.c_int]
+        L.orc_verifier_create.restype = ctypes.c_void_p
+        L.orc_verifier_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p]
         L.orc_circuit_destroy.argtypes = [ctypes.c_void_p]
         L.orc_circuit_cap.argtypes = [ctypes.c_void_p, u64p]
         L.orc_prove.restype = ctypes.c_long
@@ -141,7 +143,7 @@ class SynthCircuit:
 class OracleCircuit:
     """The CPU oracle's view of a circuit package: prove / verify with the restated qp-plonky2 algorithm."""
 
-    def __init__(self, desc, threads=0):
+    def __init__(self, desc, threads=0, verifier_only_cap=None):
         L = oracle()
         d = desc
         ng = d.num_gates
@@ -150,6 +152,15 @@ class OracleCircuit:
         arity = np.array(list(d.fri_arity_bits), dtype=np.uint32)
         digest = np.array(list(d.circuit_digest), dtype=np.uint64)
         self.desc = d
+        if verifier_only_cap is not None:
+            cap = np.ascontiguousarray(verifier_only_cap, dtype=np.uint64)
+            self.h = L.orc_verifier_create(d.degree_bits, d.num_wires, d.num_routed, d.num_constants, d.num_challenges,
+                                           d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
+                                           d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
+                                           d.fri_num_queries, d.fri_pow_bits, d.fri_num_layers, ptr(arity, u32p), ng,
+                                           ptr(tags, u32p), ptr(params), d.selector_indices, d.num_selector_groups,
+                                           d.selector_group_ranges, d.k_is, ptr(cap), ptr(digest))
+            return
         self.h = L.orc_circuit_create(d.degree_bits, d.num_wires, d.num_routed, d.num_constants, d.num_challenges,
                                       d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
                                       d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
