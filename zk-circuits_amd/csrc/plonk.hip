@@ -102,7 +102,9 @@ void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s) {
 struct Acc2 { u64 a0, a1; };
 // acc += term * alpha^idx for both challenges
 #define ACC_TERM(term_, idx_) do { u64 t__ = (term_); int i__ = (idx_); \
-    g0 = gl_add(g0, gl_mul(t__, ap0[i__])); g1 = gl_add(g1, gl_mul(t__, ap1[i__])); } while (0)
+    acc_mul(g0, t__, ap0[i__]); acc_mul(g1, t__, ap1[i__]); } while (0)
+// lazy a - b for lazy a (any u64) and canonical b
+__device__ __forceinline__ u64 sub_lazy_canon(u64 a, u64 b) { u64 d = a - b; if (a < b) d += GL_P; return d; }
 
 struct Pi4 { u64 v[4]; };
 struct Zh8 { u64 zh[8]; u64 zh_inv[8]; };
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
     u64 filter = 1;
     for (u32 i = g.grp_lo; i < g.grp_hi; i++) if ((int)i != gi) filter = gl_mul(filter, gl_sub((u64)i, sv));
     if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, sv));
-    u64 g0 = 0, g1 = 0;
+    Acc192 g0{0, 0, 0}, g1{0, 0, 0};
     switch (g.tag) {
       case QPGPU_GATE_NOOP: break;
       case QPGPU_GATE_CONSTANT:
@@ -186,7 +188,9 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
         }
         break;
       case QPGPU_GATE_POSEIDON: {
-        const u64* rc = poseidon_rc();
+        // State kept as lazy residues (poseidon_dev.h); the next round's constants ride in on the MDS accumulators, so
+        // after each mds_rc_lazy the state already equals "MDS output + round constant", which is what the wires pin.
+        const u64* rc = POSEIDON_RC_DEV;
         int k = 0;
         u64 swap = Wv(24);
         ACC_TERM(gl_mul(swap, gl_sub(swap, 1)), k); k++;
@@ -199,41 +203,37 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
         }
 #pragma unroll
         for (int i = 8; i < 12; i++) st[i] = Wv(i);
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], rc[i]);
         int round = 0;
         for (int r = 0; r < 4; r++, round++) {
-#pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
           if (r != 0) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) { u64 in = Wv(29 + 12 * (r - 1) + i); ACC_TERM(gl_sub(st[i], in), k); k++; st[i] = in; }
+            for (int i = 0; i < 12; i++) { u64 in = Wv(29 + 12 * (r - 1) + i); ACC_TERM(sub_lazy_canon(st[i], in), k); k++; st[i] = in; }
           }
 #pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
-          mds_layer(st);
+          for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+          mds_rc_lazy(st, rc + 12 * (round + 1));
         }
         for (int r = 0; r < 22; r++, round++) {
-#pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
-          u64 in = Wv(65 + r); ACC_TERM(gl_sub(st[0], in), k); k++;
-          st[0] = sbox7(in);
-          mds_layer(st);
+          u64 in = Wv(65 + r); ACC_TERM(sub_lazy_canon(st[0], in), k); k++;
+          st[0] = sbox7_lazy(in);
+          mds_rc_lazy(st, rc + 12 * (round + 1));
         }
         for (int r = 0; r < 4; r++, round++) {
 #pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+          for (int i = 0; i < 12; i++) { u64 in = Wv(87 + 12 * r + i); ACC_TERM(sub_lazy_canon(st[i], in), k); k++; st[i] = in; }
 #pragma unroll
-          for (int i = 0; i < 12; i++) { u64 in = Wv(87 + 12 * r + i); ACC_TERM(gl_sub(st[i], in), k); k++; st[i] = in; }
-#pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
-          mds_layer(st);
+          for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+          if (r < 3) mds_rc_lazy(st, rc + 12 * (round + 1)); else mds_rc_lazy(st, nullptr);
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) { ACC_TERM(gl_sub(st[i], Wv(12 + i)), k); k++; }
+        for (int i = 0; i < 12; i++) { ACC_TERM(sub_lazy_canon(st[i], Wv(12 + i)), k); k++; }
         break;
       }
       default: break;   // rejected at circuit creation
     }
-    tot0 = gl_add(tot0, gl_mul(filter, g0)); tot1 = gl_add(tot1, gl_mul(filter, g1));
+    tot0 = gl_add(tot0, gl_mul(filter, acc_reduce(g0))); tot1 = gl_add(tot1, gl_mul(filter, acc_reduce(g1)));
   }
   const u64 zi = zh.zh_inv[j & ((1u << cd.rate_bits) - 1)];
   out[L] = gl_mul(tot0, zi);
