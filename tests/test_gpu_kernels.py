@@ -86,7 +86,7 @@ def test_lde_leaf_order(log_n, shift):
     assert np.array_equal(got, exp[:, rev])            # leaf L holds the value at natural index rev(L)
 
 
-@pytest.mark.parametrize("width,leaves,cap", [(135, 512, 4), (139, 2048, 4), (84, 256, 4), (20, 64, 4), (3, 64, 2), (4, 32, 0), (32, 16, 4), (9, 4096, 4)])
+@pytest.mark.parametrize("width,leaves,cap", [(135, 512, 4), (139, 2048, 4), (24, 8192, 4), (135, 4096, 4), (84, 256, 4), (20, 64, 4), (3, 64, 2), (4, 32, 0), (32, 16, 4), (9, 4096, 4)])
 def test_merkle_tree(width, leaves, cap):
     rng = np.random.default_rng(width * 7 + leaves)
     cols = rand_felts(rng, (width, leaves))

@@ -3,6 +3,8 @@
 #include "kernels.h"
 #include <vector>
 #include <string>
+#include <chrono>
+#include "poseidon.h"
 
 namespace qp { extern thread_local std::string g_last_error; int set_err(int code, const std::string& m); }
 using namespace qp;
@@ -60,11 +62,32 @@ int qpgpu_test_merkle(const uint64_t* cols, int width, size_t num_leaves, int ca
   size_t tot = merkle_total_digests(num_leaves, cap_height);
   DevBuf c, d; HOOK_CHECK(c.alloc((size_t)width * num_leaves * 8)); HOOK_CHECK(d.alloc(tot * 32));
   HOOK_CHECK(hipMemcpy(c.p, cols, (size_t)width * num_leaves * 8, hipMemcpyHostToDevice));
-  merkle_leaves_colmajor(c.u(), num_leaves, width, num_leaves, d.u(), 0);
-  merkle_levels(d.u(), num_leaves, cap_height, 0);
+  int done = merkle_leaves_colmajor(c.u(), num_leaves, width, num_leaves, cap_height, d.u(), 0);
+  merkle_levels(d.u(), num_leaves, cap_height, 0, done);
   HOOK_CHECK(hipGetLastError());
   HOOK_CHECK(hipMemcpy(digests, d.p, tot * 32, hipMemcpyDeviceToHost));
   return 0;
+}
+
+// host-side costs that sit on the proof's critical path: ns per host permutation, and us per (tiny kernel + 512 B D2H + sync)
+double qpgpu_test_host_permute_ns(int iters) {
+  u64 st[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) poseidon_permute(st);
+  auto t1 = std::chrono::steady_clock::now();
+  volatile u64 sink = st[0]; (void)sink;
+  return std::chrono::duration<double, std::nano>(t1 - t0).count() / iters;
+}
+double qpgpu_test_sync_roundtrip_us(int iters) {
+  DevBuf d; if (d.alloc(4096) != hipSuccess) return -1;
+  u64* pin = nullptr; if (hipHostMalloc((void**)&pin, 4096, hipHostMallocDefault) != hipSuccess) return -1;
+  hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  salt_fill(d.u(), 16, 1, 0, s); (void)hipStreamSynchronize(s);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) { salt_fill(d.u(), 16, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
+  auto t1 = std::chrono::steady_clock::now();
+  (void)hipStreamDestroy(s); (void)hipHostFree(pin);
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
 }
 
 int qpgpu_test_bitrev(const uint64_t* in, int count, int log_n, uint64_t scale, uint64_t* out) {

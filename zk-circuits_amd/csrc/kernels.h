@@ -38,12 +38,13 @@ void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
 void poseidon_permute_batch(u64* states /*[count][12]*/, size_t count, hipStream_t s);
 // Leaf digests of `num_leaves` rows whose element j sits at cols + j*col_stride + leaf (column-major oracle), width felts per
 // leaf (hash_or_noop). digests: [num_leaves][4].
-void merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, hipStream_t s);
+// Returns how many levels above the leaves the launch already produced (the leaf kernel fuses levels 1-2 for big trees).
+int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s);
 // FRI layer leaves: leaf L = 2^arity_bits extension values (a[k], b[k]) k in [L*arity, (L+1)*arity), flattened a0,b0,a1,b1...
 void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s);
 // Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to
 // 2^cap_height digests. Returns (host-side) nothing; layout helper below.
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s);
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0);
 static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
   size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
 }

@@ -30,9 +30,16 @@ void poseidon_permute_batch(u64* states, size_t count, hipStream_t s) {
   hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
 }
 
-__global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests) {
+// FUSE: the block (256 consecutive leaves) also produces its 128 level-1 and 64 level-2 nodes, saving two launches whose
+// cost is pure permutation latency. It only pays when the grid is several times larger than what is resident at once
+// (measured on MI355X: at N = 2^17 all 512 blocks run in lockstep, so the fused tail costs two more permutation
+// latencies at half/quarter occupancy and the leaf+levels total gets 5 % WORSE; profiles/r01 notes). Enabled from 2^20 leaves.
+template <bool FUSE>
+__global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
+                                                         u64* level1, u64* level2) {
+  __shared__ u64 sm[FUSE ? 256 * 4 : 4];
   size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (L >= num_leaves) return;
+  if (!FUSE && L >= num_leaves) return;
   u64 st[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) st[k] = 0;
@@ -53,9 +60,50 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) digests[L * 4 + k] = st[k];
+  if (FUSE) {
+    const unsigned t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) sm[t * 4 + k] = st[k];
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) st[k] = sm[t * 8 + k];
+#pragma unroll
+      for (int k = 8; k < 12; k++) st[k] = 0;
+      poseidon_permute_dev(st);
+      size_t node = (size_t)blockIdx.x * 128 + t;
+#pragma unroll
+      for (int k = 0; k < 4; k++) level1[node * 4 + k] = st[k];
+    }
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) sm[t * 4 + k] = st[k];
+    }
+    __syncthreads();
+    if (t < 64) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) st[k] = sm[t * 8 + k];
+#pragma unroll
+      for (int k = 8; k < 12; k++) st[k] = 0;
+      poseidon_permute_dev(st);
+      size_t node = (size_t)blockIdx.x * 64 + t;
+#pragma unroll
+      for (int k = 0; k < 4; k++) level2[node * 4 + k] = st[k];
+    }
+  }
 }
-void merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, hipStream_t s) {
-  hipLaunchKernelGGL(k_leaves_colmajor, dim3((unsigned)((num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
+// Returns the number of tree levels already produced above the leaves (0 or 2).
+int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s) {
+  const bool fuse = (num_leaves % 256 == 0) && (num_leaves >> 2) >= (size_t(1) << cap_height) && num_leaves >= (size_t(1) << 20);
+  dim3 grid((unsigned)((num_leaves + 255) / 256));
+  if (fuse) {
+    hipLaunchKernelGGL(k_leaves_colmajor<true>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4,
+                       digests + (num_leaves + num_leaves / 2) * 4);
+    return 2;
+  }
+  hipLaunchKernelGGL(k_leaves_colmajor<false>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+  return 0;
 }
 
 __global__ void __launch_bounds__(256) k_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests) {
@@ -126,8 +174,9 @@ __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size
   if (p < parents && i < 4) out[p * 4 + i] = x;
 }
 static constexpr size_t COOP_MAX_PARENTS = 16384;
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s) {
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done) {
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
+  for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {
     size_t parents = cnt >> 1; u64* out = cur + cnt * 4;
     if (parents > COOP_MAX_PARENTS) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);

@@ -59,7 +59,100 @@ QP_HD void mds_layer(u64 st[12]) {
   }
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ---- host fast path (transcript: ~120 sequential permutations sit on every proof's critical path).
+// Lazy residues (any u64 congruent mod p), one 128->64 reduction per product / per MDS row, constants of the next round
+// folded into the MDS sums; canonicalised at the end. Same function as the generic code below (tests compare).
+#if defined(__clang__)
+#define QP_UNROLL_ALL _Pragma("unroll")
+#else
+#define QP_UNROLL_ALL _Pragma("GCC unroll 16")
+#endif
+namespace hostp {
+static inline u64 red128(u64 lo, u64 hi) {
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (__builtin_expect(lo < hi_hi, 0)) t0 -= GL_EPS;          // probability ~2^-32 for random data
+  u64 t1 = hi_lo * GL_EPS;
+  u64 t2 = t0 + t1;
+  t2 += (0 - (u64)(t2 < t1)) & GL_EPS;                        // ~50/50: keep it branch-free
+  return t2;
+}
+static inline u64 mul(u64 a, u64 b) { unsigned __int128 p = (unsigned __int128)a * b; return red128((u64)p, (u64)(p >> 64)); }
+static inline u64 sbox(u64 x) { u64 x2 = mul(x, x), x4 = mul(x2, x2), x3 = mul(x2, x); return mul(x3, x4); }
+static inline u64 addc(u64 x, u64 c) { u64 s = x + c; s += (0 - (u64)(s < c)) & GL_EPS; return s; }   // lazy x + canonical c
+#if defined(__x86_64__)
+} }  // close hostp, qp for the intrinsics header
+#include <immintrin.h>
+namespace qp { namespace hostp {
+// AVX2: the 12 row sums of each 32-bit half are three 4-lane vectors; vpmuludq does four 32x32->64 products at a time.
+__attribute__((target("avx2"))) static inline void mds_rc_avx2(u64 st[12], const u64* rc) {
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  alignas(32) u64 lo2[24], hi2[24], sl[12], sh[12];
+  for (int i = 0; i < 12; i++) { lo2[i] = lo2[i + 12] = st[i] & GL_EPS; hi2[i] = hi2[i + 12] = st[i] >> 32; }
+  __m256i l0 = _mm256_setzero_si256(), l1 = l0, l2 = l0, h0 = l0, h1 = l0, h2 = l0;
+  for (int i = 0; i < 12; i++) {
+    const __m256i c = _mm256_set1_epi64x((long long)C[i]);
+    l0 = _mm256_add_epi64(l0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i)), c));
+    l1 = _mm256_add_epi64(l1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i + 4)), c));
+    l2 = _mm256_add_epi64(l2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i + 8)), c));
+    h0 = _mm256_add_epi64(h0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i)), c));
+    h1 = _mm256_add_epi64(h1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i + 4)), c));
+    h2 = _mm256_add_epi64(h2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i + 8)), c));
+  }
+  _mm256_store_si256((__m256i*)sl, l0); _mm256_store_si256((__m256i*)(sl + 4), l1); _mm256_store_si256((__m256i*)(sl + 8), l2);
+  _mm256_store_si256((__m256i*)sh, h0); _mm256_store_si256((__m256i*)(sh + 4), h1); _mm256_store_si256((__m256i*)(sh + 8), h2);
+  sl[0] += lo2[0] * 8; sh[0] += hi2[0] * 8;
+  for (int r = 0; r < 12; r++) {
+    u64 c = rc ? rc[r] : 0;
+    u64 a = sl[r] + (c & GL_EPS), b = sh[r] + (c >> 32);
+    u64 t = a + (b >> 32) * GL_EPS;
+    u64 add = b << 32;
+    u64 v = t + add;
+    v += (0 - (u64)(v < add)) & GL_EPS;
+    st[r] = v;
+  }
+}
+static inline bool have_avx2() { static const bool ok = __builtin_cpu_supports("avx2"); return ok; }
+#endif
+static inline void mds_rc(u64 st[12], const u64* rc) {
+#if defined(__x86_64__)
+  if (have_avx2()) { mds_rc_avx2(st, rc); return; }
+#endif
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 lo[12], hi[12], out[12];
+  QP_UNROLL_ALL for (int i = 0; i < 12; i++) { lo[i] = st[i] & GL_EPS; hi[i] = st[i] >> 32; }
+  QP_UNROLL_ALL for (int r = 0; r < 12; r++) {
+    u64 c = rc ? rc[r] : 0;
+    u64 sl = c & GL_EPS, sh = c >> 32;
+    QP_UNROLL_ALL for (int i = 0; i < 12; i++) { sl += lo[(i + r) % 12] * C[i]; sh += hi[(i + r) % 12] * C[i]; }
+    if (r == 0) { sl += lo[0] * 8; sh += hi[0] * 8; }
+    // value = sl + 2^32 sh, both < 2^43
+    u64 t = sl + (sh >> 32) * GL_EPS;                         // no overflow
+    u64 add = sh << 32;
+    u64 v = t + add;
+    v += (0 - (u64)(v < add)) & GL_EPS;
+    out[r] = v;
+  }
+  QP_UNROLL_ALL for (int r = 0; r < 12; r++) st[r] = out[r];
+}
+}
+inline void poseidon_permute(u64 st[12]) {
+  const u64* rc = POSEIDON_RC_HOST;
+  QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::addc(st[i], rc[i]);
+  int r = 0;
+  for (; r < 4; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
+  for (; r < 26; r++) { st[0] = hostp::sbox(st[0]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
+  for (; r < 29; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
+  QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]);
+  hostp::mds_rc(st, nullptr);
+  QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] -= (0 - (u64)(st[i] >= GL_P)) & GL_P;
+}
+// literal round-by-round form (used by the witness synthesiser's traces and by tests)
+inline void poseidon_permute_generic(u64 st[12]) {
+#else
 QP_HD void poseidon_permute(u64 st[12]) {
+#endif
   const u64* rc = poseidon_rc();
   int r = 0;
   for (int k = 0; k < 4; k++, r++) {

@@ -172,10 +172,11 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     else salt_fill(lde + (size_t)cols * N, N, salt_seed, oracle - 1, s);
     width += 4;
   }
+  int done = 0;
   { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
-    merkle_leaves_colmajor(lde, N, width, N, dig, s); }
+    done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
-    merkle_levels(dig, N, c->cap_h, s); }
+    merkle_levels(dig, N, c->cap_h, s, done); }
   size_t cap_off = merkle_total_digests(N, c->cap_h) - (size_t(1) << c->cap_h);
   if (cap_host) (void)hipMemcpyAsync(cap_host, dig + cap_off * 4, (size_t(32)) << c->cap_h, hipMemcpyDeviceToHost, s);
 }
