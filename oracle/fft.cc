@@ -3,6 +3,7 @@
 #include "plonk.h"
 #include <map>
 #include <mutex>
+#include <omp.h>
 
 namespace orc {
 
@@ -23,13 +24,16 @@ void ntt(std::vector<u64>& a, bool inverse) {
   int lg = log2_exact(n);
   const std::vector<u64>& tw = twiddles(lg, inverse);
   for (size_t i = 0; i < n; i++) { size_t j = rev_bits((uint32_t)i, lg); if (i < j) std::swap(a[i], a[j]); }
+  const bool par = n >= (size_t(1) << 15) && !omp_in_parallel();   // the few big single-column transforms (quotient, FRI)
+  u64* A = a.data(); const u64* TW = tw.data();
   for (int s = 1; s <= lg; s++) {
     size_t m = size_t(1) << s, half = m >> 1, step = n / m;
-    for (size_t k = 0; k < n; k += m)
-      for (size_t j = 0; j < half; j++) {
-        u64 t = gl_mul(tw[j * step], a[k + j + half]), u = a[k + j];
-        a[k + j] = gl_add(u, t); a[k + j + half] = gl_sub(u, t);
-      }
+#pragma omp parallel for schedule(static) if (par)
+    for (size_t q = 0; q < n / 2; q++) {
+      size_t k = (q / half) * m, j = q % half;
+      u64 t = gl_mul(TW[j * step], A[k + j + half]), u = A[k + j];
+      A[k + j] = gl_add(u, t); A[k + j + half] = gl_sub(u, t);
+    }
   }
   if (inverse) { u64 ni = gl_inv((u64)n); for (auto& x : a) x = gl_mul(x, ni); }
 }

@@ -1,6 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see poseidon.h).
 #include "poseidon.h"
 #include <mutex>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace orc {
 
@@ -57,23 +60,77 @@ const u64* poseidon_round_constants() {
   return RC;
 }
 
-// Same round function as the generic template (add constants -> S-box -> MDS), with the MDS row accumulated
-// in 128 bits and reduced once (the constants are < 2^6, so 12 products fit easily).
+// Same round function as the generic template (add constants -> S-box -> MDS), written for throughput because this file
+// is also bench.py's CPU baseline: state elements are lazy residues (any u64 congruent mod p), the MDS row sums are taken
+// on the 32-bit halves (AVX2 vpmuludq when available, else scalar) with the next round's constants folded in, and there
+// is one 128->64 reduction per product / per row. Tests pin it against the literal form below and the reference KATs.
+namespace {
+inline u64 red128_lazy(u64 lo, u64 hi) {
+  u64 hh = hi >> 32, hl = hi & EPS;
+  u64 t0 = lo - hh; if (__builtin_expect(lo < hh, 0)) t0 -= EPS;
+  u64 t1 = hl * EPS, t2 = t0 + t1;
+  t2 += (0 - (u64)(t2 < t1)) & EPS;
+  return t2;
+}
+inline u64 mul_lazy(u64 a, u64 b) { u128 p = (u128)a * b; return red128_lazy((u64)p, (u64)(p >> 64)); }
+inline u64 sbox_lazy(u64 x) { u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x2, x); return mul_lazy(x3, x4); }
+inline void mds_epilogue(u64 st[12], const u64 sl[12], const u64 sh[12], const u64* rc) {
+  for (int r = 0; r < 12; r++) {
+    u64 c = rc ? rc[r] : 0;
+    u64 a = sl[r] + (c & EPS), b = sh[r] + (c >> 32);
+    u64 t = a + (b >> 32) * EPS, add = b << 32, v = t + add;
+    v += (0 - (u64)(v < add)) & EPS;
+    st[r] = v;
+  }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void mds_rc_avx2(u64 st[12], const u64* rc) {
+  alignas(32) u64 lo2[24], hi2[24], sl[12], sh[12];
+  for (int i = 0; i < 12; i++) { lo2[i] = lo2[i + 12] = st[i] & EPS; hi2[i] = hi2[i + 12] = st[i] >> 32; }
+  __m256i l0 = _mm256_setzero_si256(), l1 = l0, l2 = l0, h0 = l0, h1 = l0, h2 = l0;
+  for (int i = 0; i < 12; i++) {
+    const __m256i c = _mm256_set1_epi64x((long long)MDS_CIRC[i]);
+    l0 = _mm256_add_epi64(l0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i)), c));
+    l1 = _mm256_add_epi64(l1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i + 4)), c));
+    l2 = _mm256_add_epi64(l2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo2 + i + 8)), c));
+    h0 = _mm256_add_epi64(h0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i)), c));
+    h1 = _mm256_add_epi64(h1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i + 4)), c));
+    h2 = _mm256_add_epi64(h2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi2 + i + 8)), c));
+  }
+  _mm256_store_si256((__m256i*)sl, l0); _mm256_store_si256((__m256i*)(sl + 4), l1); _mm256_store_si256((__m256i*)(sl + 8), l2);
+  _mm256_store_si256((__m256i*)sh, h0); _mm256_store_si256((__m256i*)(sh + 4), h1); _mm256_store_si256((__m256i*)(sh + 8), h2);
+  sl[0] += lo2[0] * MDS_DIAG[0]; sh[0] += hi2[0] * MDS_DIAG[0];
+  mds_epilogue(st, sl, sh, rc);
+}
+#endif
+void mds_rc_scalar(u64 st[12], const u64* rc) {
+  u64 lo[12], hi[12], sl[12], sh[12];
+  for (int i = 0; i < 12; i++) { lo[i] = st[i] & EPS; hi[i] = st[i] >> 32; }
+  for (int r = 0; r < 12; r++) {
+    u64 a = lo[r] * MDS_DIAG[r], b = hi[r] * MDS_DIAG[r];
+    for (int i = 0; i < 12; i++) { a += lo[(i + r) % 12] * MDS_CIRC[i]; b += hi[(i + r) % 12] * MDS_CIRC[i]; }
+    sl[r] = a; sh[r] = b;
+  }
+  mds_epilogue(st, sl, sh, rc);
+}
+inline void mds_rc(u64 st[12], const u64* rc) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) { mds_rc_avx2(st, rc); return; }
+#endif
+  mds_rc_scalar(st, rc);
+}
+}
 void poseidon_permute(u64 st[12]) {
   const u64* rc = poseidon_round_constants();
+  for (int i = 0; i < 12; i++) { u64 s = st[i] + rc[i]; s += (0 - (u64)(s < rc[i])) & EPS; st[i] = s; }
   for (int r = 0; r < N_ROUNDS; r++) {
-    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * r + i]);
     bool full = r < N_FULL_HALF || r >= N_FULL_HALF + N_PARTIAL;
-    if (full) for (int i = 0; i < 12; i++) st[i] = sbox7(FB(st[i])).v;
-    else st[0] = sbox7(FB(st[0])).v;
-    u64 out[12];
-    for (int k = 0; k < 12; k++) {
-      u128 acc = (u128)st[k] * MDS_DIAG[k];
-      for (int i = 0; i < 12; i++) acc += (u128)st[(i + k) % 12] * MDS_CIRC[i];
-      out[k] = gl_red128(acc);
-    }
-    memcpy(st, out, sizeof out);
+    if (full) for (int i = 0; i < 12; i++) st[i] = sbox_lazy(st[i]);
+    else st[0] = sbox_lazy(st[0]);
+    mds_rc(st, r + 1 < N_ROUNDS ? rc + 12 * (r + 1) : nullptr);
   }
+  for (int i = 0; i < 12; i++) if (st[i] >= P) st[i] -= P;
 }
 
 // Literal (slow) form through the field-generic template; tests compare it with poseidon_permute.

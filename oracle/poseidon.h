@@ -38,4 +38,15 @@ template <class T> static inline void mds_layer_t(T st[12]) {
   for (int r = 0; r < 12; r++) st[r] = out[r];
 }
 
+// Base-field specialisation (the CPU prover evaluates the Poseidon gate on every LDE point): 128-bit row accumulation.
+template <> inline void mds_layer_t<FB>(FB st[12]) {
+  u64 out[12];
+  for (int r = 0; r < 12; r++) {
+    u128 acc = (u128)st[r].v * MDS_DIAG[r];
+    for (int i = 0; i < 12; i++) acc += (u128)st[(i + r) % 12].v * MDS_CIRC[i];
+    out[r] = gl_red128(acc);
+  }
+  for (int r = 0; r < 12; r++) st[r] = FB(out[r]);
+}
+
 } // namespace orc

@@ -8,6 +8,9 @@
 #include "plonk.h"
 #include <omp.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace orc {
 
@@ -19,19 +22,46 @@ struct Commitment {
   size_t width = 0; MerkleTree tree;
 };
 
-// PolynomialBatch::from_coeffs: LDE x2^rate on coset GEN, transpose, bit-reverse rows, append salt, Merkle.
+// In-place DIF butterflies without the final bit-reversal: natural-order input, bit-reversed-order output.
+void ntt_dif_noperm(u64* a, size_t n, const std::vector<u64>& tw /* w_n^j, j < n/2 */) {
+  for (size_t half = n >> 1, step = 1; half >= 1; half >>= 1, step <<= 1)
+    for (size_t k = 0; k < n; k += 2 * half)
+      for (size_t j = 0; j < half; j++) {
+        u64 u = a[k + j], v = a[k + j + half];
+        a[k + j] = gl_add(u, v); a[k + j + half] = gl_mul(gl_sub(u, v), tw[j * step]);
+      }
+}
+// PolynomialBatch::from_coeffs: LDE x2^rate on coset GEN, rows in bit-reversed order, salt appended, Merkle tree.
+// Written for the CPU baseline: the leaf-order LDE of a column is 2^rate independent size-n DIF transforms (block rev(c)
+// holds coset c, exactly the layout upstream reaches with transpose + reverse_index_bits), produced column-major with
+// sequential writes and then transposed to rows in cache-sized tiles.
 Commitment commit_coeffs(std::vector<std::vector<u64>>&& coeffs, int rate_bits, int cap_height, const u64* salt /*[4][N] or null*/) {
   Commitment cm; cm.coeffs = std::move(coeffs);
   size_t cols = cm.coeffs.size(), n = cm.coeffs[0].size(), N = n << rate_bits;
-  int lgN = log2_exact(N); int s = salt ? 4 : 0;
+  int lgn = log2_exact(n), lgN = lgn + rate_bits; int s = salt ? 4 : 0;
   cm.width = cols + s; cm.rows.assign(N * cm.width, 0);
-#pragma omp parallel for schedule(dynamic, 1)
-  for (size_t c = 0; c < cols; c++) {
-    std::vector<u64> v = coset_lde(cm.coeffs[c], rate_bits, GEN);
-    for (size_t j = 0; j < N; j++) cm.rows[(size_t)rev_bits((uint32_t)j, lgN) * cm.width + c] = v[j];
+  std::vector<u64> tw(n / 2 ? n / 2 : 1); { u64 w = gl_root(lgn), x = 1; for (size_t j = 0; j < n / 2; j++) { tw[j] = x; x = gl_mul(x, w); } }
+  const size_t cosets = size_t(1) << rate_bits;
+  std::vector<u64> scale(N);   // scale[c*n + i] = (GEN * w_N^c)^i
+  { u64 wN = gl_root(lgN);
+#pragma omp parallel for schedule(static)
+    for (size_t c = 0; c < cosets; c++) { u64 base = gl_mul(GEN, gl_pow(wN, c)), x = 1; for (size_t i = 0; i < n; i++) { scale[c * n + i] = x; x = gl_mul(x, base); } } }
+  std::vector<u64> cm_lde(cols * N);
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (size_t c = 0; c < cols; c++)
+    for (size_t co = 0; co < cosets; co++) {
+      u64* dst = &cm_lde[c * N + (size_t)rev_bits((uint32_t)co, rate_bits) * n];
+      const u64* src = cm.coeffs[c].data(); const u64* sc = &scale[co * n];
+      for (size_t i = 0; i < n; i++) dst[i] = gl_mul(src[i], sc[i]);
+      ntt_dif_noperm(dst, n, tw);
+    }
+  const size_t TILE = 64;
+#pragma omp parallel for schedule(static)
+  for (size_t L0 = 0; L0 < N; L0 += TILE) {
+    size_t L1 = L0 + TILE < N ? L0 + TILE : N;
+    for (size_t c = 0; c < cols; c++) { const u64* src = &cm_lde[c * N]; for (size_t L = L0; L < L1; L++) cm.rows[L * cm.width + c] = src[L]; }
+    for (int k = 0; k < s; k++) for (size_t L = L0; L < L1; L++) cm.rows[L * cm.width + cols + k] = salt[(size_t)k * N + L];
   }
-  for (int k = 0; k < s; k++)
-    for (size_t L = 0; L < N; L++) cm.rows[L * cm.width + cols + k] = salt[(size_t)k * N + L];
   cm.tree = merkle_build(cm.rows.data(), N, cm.width, cap_height);
   return cm;
 }
@@ -67,7 +97,11 @@ Preprocessed preprocess(const Common& c, const u64* cs, int threads) {
   return p;
 }
 
+namespace { struct StageTimer { bool on; std::chrono::steady_clock::time_point t; StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* name) { if (!on) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[oracle] %-22s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(n - t).count()); t = n; } }; }
+
 Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
+  StageTimer tm;
   const Common& c = *in.common;
   if (in.threads > 0) omp_set_num_threads(in.threads);
   const size_t n = c.n(), N = c.lde_n();
@@ -85,6 +119,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
   for (int j = 0; j < W; j++) wv[j].assign(in.wires + (size_t)j * n, in.wires + (size_t)(j + 1) * n);
   Commitment wires = commit_values(std::move(wv), c.rate_bits, c.cap_height, salt[0]);
   pf.wires_cap = wires.tree.cap();
+  tm.lap("wires commit");
 
   Challenger ch;
   ch.observe_hash(in.circuit_digest); ch.observe_hash(pi_hash); ch.observe_cap(pf.wires_cap);
@@ -125,7 +160,9 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
       }
     }
   }
+  tm.lap("z/partial products");
   Commitment zs = commit_values(std::move(zpp), c.rate_bits, c.cap_height, salt[1]);
+  tm.lap("zs commit");
   pf.zs_pp_cap = zs.tree.cap();
   ch.observe_cap(pf.zs_pp_cap);
   for (auto& a : alphas) a = ch.challenge();
@@ -136,33 +173,47 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
     u64 wN = gl_root(lgN), w8 = gl_root(c.rate_bits);
     u64 gn = gl_pow(GEN, n);
     std::vector<u64> zh_inv(size_t(1) << c.rate_bits);
-    { u64 t = 1; for (size_t k = 0; k < zh_inv.size(); k++) { zh_inv[k] = gl_inv(gl_sub(gl_mul(gn, t), 1)); t = gl_mul(t, w8); } }
+    std::vector<u64> w8pow(zh_inv.size());
+    { u64 t = 1; for (size_t k = 0; k < zh_inv.size(); k++) { w8pow[k] = t; zh_inv[k] = gl_inv(gl_sub(gl_mul(gn, t), 1)); t = gl_mul(t, w8); } }
     u64 n_inv = gl_inv((u64)n);
     int nterms = nch + nch * nchunks + c.num_gate_constraints;
+    // x_j = GEN * w_N^j and 1/(x_j - 1) for all points (running products + one inversion per chunk)
+    std::vector<u64> xs(N), xinv(N);
+    const size_t CH = 1024;
+#pragma omp parallel for schedule(static)
+    for (size_t j0 = 0; j0 < N; j0 += CH) {
+      size_t j1 = j0 + CH < N ? j0 + CH : N;
+      u64 x = gl_mul(GEN, gl_pow(wN, j0));
+      u64 run = 1;
+      for (size_t j = j0; j < j1; j++) { xs[j] = x; xinv[j] = run; run = gl_mul(run, gl_sub(x, 1)); x = gl_mul(x, wN); }
+      u64 inv = gl_inv(run);
+      for (size_t j = j1; j-- > j0;) { u64 d = gl_sub(xs[j], 1); xinv[j] = gl_mul(xinv[j], inv); inv = gl_mul(inv, d); }
+    }
 #pragma omp parallel
     {
       std::vector<FB> consts(NC), wv2(W), gate(c.num_gate_constraints), terms(nterms);
 #pragma omp for schedule(static)
       for (size_t j = 0; j < N; j++) {
         size_t L = rev_bits((uint32_t)j, lgN), Ln = rev_bits((uint32_t)((j + (size_t(1) << c.rate_bits)) % N), lgN);
-        u64 x = gl_mul(GEN, gl_pow(wN, j));
+        u64 x = xs[j];
         const u64* cs = &pre.lde_rows[L * S]; const u64* wr = &wires.rows[L * wires.width];
         const u64* zr = &zs.rows[L * zs.width]; const u64* zn = &zs.rows[Ln * zs.width];
         for (int k = 0; k < NC; k++) consts[k] = FB(cs[k]);
         for (int k = 0; k < W; k++) wv2[k] = FB(wr[k]);
         FB pih[4] = {FB(pi_hash[0]), FB(pi_hash[1]), FB(pi_hash[2]), FB(pi_hash[3])};
         eval_gate_constraints<FB>(c, consts.data(), wv2.data(), pih, gate.data());
-        u64 zh = gl_sub(gl_mul(gn, gl_pow(w8, j % zh_inv.size())), 1);
-        u64 l0 = gl_mul(zh, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
+        u64 zh = gl_sub(gl_mul(gn, w8pow[j % zh_inv.size()]), 1);
+        u64 l0 = gl_mul(zh, gl_mul(n_inv, xinv[j]));
         int t = 0;
         for (int i = 0; i < nch; i++) terms[t++] = FB(gl_mul(l0, gl_sub(zr[i], 1)));
         for (int i = 0; i < nch; i++) {
           u64 prev = zr[i];
+          const u64 bx = gl_mul(betas[i], x);
           for (int k = 0; k < nchunks; k++) {
             u64 next = k < np ? zr[nch + i * np + k] : zn[i];
             u64 num = 1, den = 1;
             for (int jj = k * deg; jj < (k + 1) * deg && jj < R; jj++) {
-              num = gl_mul(num, gl_add(gl_add(wr[jj], gl_mul(betas[i], gl_mul(c.k_is[jj], x))), gammas[i]));
+              num = gl_mul(num, gl_add(gl_add(wr[jj], gl_mul(bx, c.k_is[jj])), gammas[i]));
               den = gl_mul(den, gl_add(gl_add(wr[jj], gl_mul(betas[i], cs[NC + jj])), gammas[i]));
             }
             terms[t++] = FB(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
@@ -178,6 +229,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
       }
     }
   }
+  tm.lap("quotient eval");
   std::vector<std::vector<u64>> qchunks;
   {
     u64 ginv = gl_inv(GEN);
@@ -187,7 +239,9 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
       for (int m = 0; m < deg; m++) qchunks.emplace_back(qvals[i].begin() + m * n, qvals[i].begin() + (m + 1) * n);
     }
   }
+  tm.lap("quotient intt");
   Commitment quot = commit_coeffs(std::move(qchunks), c.rate_bits, c.cap_height, salt[2]);
+  tm.lap("quotient commit");
   pf.quotient_cap = quot.tree.cap();
   ch.observe_cap(pf.quotient_cap);
   Ext zeta = ch.challenge_ext();
@@ -212,6 +266,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
   for (auto* v : {&pf.o_constants, &pf.o_sigmas, &pf.o_wires, &pf.o_zs, &pf.o_pp, &pf.o_quotient}) for (Ext e : *v) ch.observe_ext(e);
   for (Ext e : pf.o_zs_next) ch.observe_ext(e);
 
+  tm.lap("openings");
   // ---- 9. FRI: batch combine in coefficient space (prove_openings)
   Ext fa = ch.challenge_ext();
   std::vector<Ext> final_poly(n, ex(0));
@@ -242,6 +297,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
   std::vector<Ext> values = coeffs;
   ext_coset_ntt(values, GEN);
 
+  tm.lap("fri combine + lde");
   // ---- fri_committed_trees
   std::vector<MerkleTree> fri_trees; std::vector<std::vector<u64>> fri_leaves;
   u64 shift = GEN;
@@ -264,6 +320,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
   pf.final_poly = coeffs;
   for (Ext e : pf.final_poly) ch.observe_ext(e);
 
+  tm.lap("fri layers");
   // ---- PoW (canonical choice of this build: the smallest valid witness; upstream's parallel find_any is not deterministic)
   if (in.have_pow) pf.pow_witness = in.pow_witness;
   else {
@@ -284,6 +341,7 @@ Proof prove(const ProverInputs& in, const Preprocessed& pre, std::string* err) {
   u64 pow_response = ch.challenge();
   { int lz = pow_response == 0 ? 64 : __builtin_clzll(pow_response); if (lz < c.pow_bits) { if (err) *err = "supplied pow_witness invalid"; return Proof(); } }
 
+  tm.lap("pow");
   // ---- queries
   const std::vector<u64>* rows[4] = {&pre.lde_rows, &wires.rows, &zs.rows, &quot.rows};
   size_t widths[4] = {(size_t)S, wires.width, zs.width, quot.width};
