@@ -211,6 +211,7 @@ def qpgpu():
         L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.qpgpu_test_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
         L.qpgpu_test_merkle.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_intt_natural.argtypes = [u64p, ctypes.c_int, ctypes.c_int, u64p]
         L.qpgpu_test_bitrev.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
         L.qpgpu_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.qpgpu_ctx_destroy.argtypes = [ctypes.c_void_p]

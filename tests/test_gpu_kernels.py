@@ -69,7 +69,20 @@ def test_ntt_dit_forward_and_dif_inverse(log_n):
     assert np.array_equal(chk, inv[:, :64])
 
 
-@pytest.mark.parametrize("log_n,shift", [(3, GEN), (6, GEN), (10, 7), (13, GEN), (14, GEN), (15, GEN)])
+@pytest.mark.parametrize("log_n", [4, 8, 9, 10, 11, 12, 13, 14, 15])
+def test_intt_values_to_natural_coefficients(log_n):
+    rng = np.random.default_rng(300 + log_n)
+    n = 1 << log_n
+    vals = rand_felts(rng, (3, n))
+    exp = vals.copy()
+    for c in range(3):
+        oracle().orc_ntt(ptr(exp[c]), n, 1)
+    got = np.zeros_like(vals)
+    gpu_check(qpgpu().qpgpu_test_intt_natural(ptr(vals), 3, log_n, ptr(got)))
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("log_n,shift", [(3, GEN), (6, GEN), (9, GEN), (10, 7), (11, GEN), (12, GEN), (13, GEN), (14, GEN), (15, GEN)])
 def test_lde_leaf_order(log_n, shift):
     rng = np.random.default_rng(200 + log_n)
     n = 1 << log_n

@@ -90,6 +90,37 @@ double qpgpu_test_sync_roundtrip_us(int iters) {
   return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
 }
 
+// values [count][n] natural -> coefficients [count][n] natural (the production witness/Z iNTT path)
+int qpgpu_test_intt_natural(const uint64_t* vals, int count, int log_n, uint64_t* coeffs) {
+  size_t n = size_t(1) << log_n;
+  DevBuf a, b, t, rt; HOOK_CHECK(a.alloc(count * n * 8)); HOOK_CHECK(b.alloc(count * n * 8)); HOOK_CHECK(t.alloc(count * n * 8)); HOOK_CHECK(rt.alloc((n / 2 + 1) * 8));
+  HOOK_CHECK(hipMemcpy(a.p, vals, count * n * 8, hipMemcpyHostToDevice));
+  build_root_table(rt.u(), log_n, 0);
+  NttPlan pl{rt.u(), log_n};
+  if (ntt16_supported(log_n)) ntt16_run(a.u(), n, b.u(), n, count, log_n, 0, true, true, nullptr, gl_inv((u64)n), pl, 0);
+  else { ntt_copy(a.u(), n, t.u(), n, count, log_n, false, true, pl, 0); bitrev_permute(t.u(), n, b.u(), n, count, log_n, gl_inv((u64)n), 0); }
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(coeffs, b.p, count * n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Timing hook: ms per launch of the x8 coset LDE of `count` columns of 2^log_n coefficients (device-resident data).
+double qpgpu_bench_lde(int count, int log_n, int iters, int force_generic) {
+  size_t n = size_t(1) << log_n, N = n << 3; int log_N = log_n + 3;
+  DevBuf in, o, rt, sc; if (in.alloc(count * n * 8) != hipSuccess || o.alloc(count * N * 8) != hipSuccess || rt.alloc((N / 2 + 1) * 8) != hipSuccess || sc.alloc(N * 8) != hipSuccess) return -1;
+  (void)hipMemset(in.p, 1, count * n * 8);
+  build_root_table(rt.u(), log_N, 0);
+  NttPlan pl{rt.u(), log_N};
+  build_lde_scale(sc.u(), log_n, 3, GL_GEN, pl, 0);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  auto run = [&]() { if (force_generic) lde_batch_generic(in.u(), n, o.u(), N, count, log_n, 3, sc.u(), pl, 0); else lde_batch(in.u(), n, o.u(), N, count, log_n, 3, sc.u(), pl, 0); };
+  run(); (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0); for (int i = 0; i < iters; i++) run(); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ms / iters;
+}
+
 int qpgpu_test_bitrev(const uint64_t* in, int count, int log_n, uint64_t scale, uint64_t* out) {
   size_t n = size_t(1) << log_n;
   DevBuf a, b; HOOK_CHECK(a.alloc(count * n * 8)); HOOK_CHECK(b.alloc(count * n * 8));

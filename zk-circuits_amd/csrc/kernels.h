@@ -28,9 +28,16 @@ void ntt_copy(const u64* in, size_t in_stride, u64* out, size_t out_stride, int 
 // block rev(c) holds the size-n DIF transform of coset c. scale = build_lde_scale table.
 void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
                const u64* scale, const NttPlan& pl, hipStream_t s);
+void lde_batch_generic(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
+                       const u64* scale, const NttPlan& pl, hipStream_t s);   // tiled multi-pass kernel only (any size)
 // out[i] = in[rev(i)] * scale  for `count` columns
 void bitrev_permute(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, u64 scale, hipStream_t s);
 
+// LDS-resident radix-16 path (ntt16.hip) for 2^9 <= n <= 2^14: in -> out, `count` columns x 2^log_cosets coset blocks
+// (block rev(c) of an output column holds coset c). out_natural: write natural-order results (bit-reversal done from LDS).
+bool ntt16_supported(int log_n);
+void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, bool inverse,
+               bool out_natural, const u64* pre, u64 scale, const NttPlan& pl, hipStream_t s);
 // cols[k][L] = salt_value(seed, (oracle*4 + k)*N + L) for k < 4 (salt.h)
 void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
 

@@ -152,9 +152,15 @@ void ntt_copy(const u64* in, size_t in_stride, u64* out, size_t out_stride, int 
   run_passes(in, in_stride, out, out_stride, count, log_n, 0, dit, inverse, nullptr, nullptr, pl, s);
 }
 
+void lde_batch_generic(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
+                       const u64* scale, const NttPlan& pl, hipStream_t s) {
+  if (count <= 0) return;
+  run_passes(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, nullptr, pl, s);
+}
 void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
                const u64* scale, const NttPlan& pl, hipStream_t s) {
   if (count <= 0) return;
+  if (ntt16_supported(log_n)) { ntt16_run(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, 1, pl, s); return; }
   run_passes(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, nullptr, pl, s);
 }
 

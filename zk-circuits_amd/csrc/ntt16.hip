@@ -1,0 +1,158 @@
+// LDS-resident radix-16 Goldilocks NTT for 2^9 <= n <= 2^14 (one global read + one global write per element).
+//
+// One workgroup owns one transform (one column, one LDE coset): n/16 threads, 16 elements per thread. The transform is the
+// in-place DIF factorisation n = 16 x 16 x ... x 2^rem: each step gathers 16 elements at stride m = N_s/16 from LDS into
+// registers, runs a 16-point DIF (constant 16th-root twiddles), multiplies output f by w_{N_s}^{u f} (table lookup) and
+// scatters back in place with the sub-index bit-reversed, so after the last step LDS holds the transform in bit-reversed
+// order (= Merkle leaf order). The LDS image is padded one slot per 16 (pos(e) = e + e/16) so that both the stride-m
+// gathers and the final contiguous groups are (nearly) bank-conflict free for 8-byte accesses.
+// Used for: witness/Z iNTT (inverse, natural-order output written straight from LDS, no separate bit-reversal pass) and the
+// x8 coset LDE (prescale fused into the load). Larger transforms (quotient iNTT at 2^17, the 2^20 stress config) stay on
+// the tiled multi-pass kernel in ntt.hip. Rows a3/a4 of SURVEY.md §8.
+#include "kernels.h"
+#include "poseidon_dev.h"
+
+namespace qp {
+
+struct W16 { u64 w[8]; };   // w[j] = W^j, W = primitive 16th root (or its inverse)
+
+__device__ __forceinline__ u64 mulc(u64 a, u64 b) { return canon(mul_lazy(a, b)); }
+__device__ __forceinline__ u64 root_pow16(const u64* rt, int log_M, u64 e) {
+  u64 M = 1ULL << log_M; e &= (M - 1); u64 half = M >> 1;
+  return e < half ? rt[e] : gl_neg(rt[e - half]);
+}
+__device__ __forceinline__ unsigned lpos(unsigned e) { return e + (e >> 4); }
+
+// 16-point DIF, output in bit-reversed register order: x[r] = sum_k in[k] W^(k * rev4(r))
+__device__ __forceinline__ void dft16(u64 x[16], const W16& c) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) { u64 a = x[k], b = x[k + 8]; x[k] = gl_add(a, b); u64 d = gl_sub(a, b); x[k + 8] = k ? mulc(d, c.w[k]) : d; }
+#pragma unroll
+  for (int h = 0; h < 16; h += 8)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { u64 a = x[h + k], b = x[h + k + 4]; x[h + k] = gl_add(a, b); u64 d = gl_sub(a, b); x[h + k + 4] = k ? mulc(d, c.w[2 * k]) : d; }
+#pragma unroll
+  for (int q = 0; q < 16; q += 4)
+#pragma unroll
+    for (int k = 0; k < 2; k++) { u64 a = x[q + k], b = x[q + k + 2]; x[q + k] = gl_add(a, b); u64 d = gl_sub(a, b); x[q + k + 2] = k ? mulc(d, c.w[4]) : d; }
+#pragma unroll
+  for (int p = 0; p < 16; p += 2) { u64 a = x[p], b = x[p + 1]; x[p] = gl_add(a, b); x[p + 1] = gl_sub(a, b); }
+}
+
+struct Ntt16Args {
+  const u64* in; size_t in_stride;    // column c at in + c*in_stride (n elements, natural order)
+  u64* out; size_t out_stride;        // column c (and coset block) at out + c*out_stride + rev(coset)*n
+  const u64* pre;                     // optional [cosets][n] prescale
+  const u64* rt; int log_M;
+  W16 w16; u64 scale;                 // scale applied on store (1 = none)
+  int log_cosets, inverse, out_natural;
+};
+
+template <int K>
+__global__ void __launch_bounds__(1 << (K - 4)) k_ntt16(Ntt16Args a) {
+  extern __shared__ u64 sm[];
+  constexpr unsigned n = 1u << K, T = n >> 4;
+  constexpr int S = K / 4, REM = K % 4;
+  const unsigned t = threadIdx.x;
+  const unsigned tid = blockIdx.y, col = tid >> a.log_cosets, co = tid & ((1u << a.log_cosets) - 1);
+  const u64* src = a.in + (size_t)col * a.in_stride;
+  u64* dst = a.out + (size_t)col * a.out_stride + (size_t)rev_bits(co, a.log_cosets) * n;
+  const u64* pre = a.pre ? a.pre + (size_t)co * n : nullptr;
+  const u64 Mfull = 1ULL << a.log_M;
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { u64 v = src[k * T + t]; if (pre) v = mulc(v, pre[k * T + t]); x[k] = v; }
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned Ns_log = K - 4 * s, m = 1u << (Ns_log - 4);
+    const unsigned B = t >> (Ns_log - 4), u = t & (m - 1);
+    const unsigned base = (B << Ns_log) + u;
+    if (s > 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[k] = sm[lpos(base + k * m)];
+    }
+    dft16(x, a.w16);
+    if (m > 1) {
+      // x[r] holds frequency f = rev4(r): multiply by w_{N_s}^{u f}
+      const u64 unit = (u64)u << (a.log_M - Ns_log);
+#pragma unroll
+      for (int r = 1; r < 16; r++) {
+        const unsigned f = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+        u64 e = unit * f;
+        if (a.inverse) e = Mfull - e;
+        x[r] = mulc(x[r], root_pow16(a.rt, a.log_M, e));
+      }
+    }
+    // in place: a thread writes exactly the 16 slots it read, so no barrier is needed between its reads and writes
+#pragma unroll
+    for (int r = 0; r < 16; r++) sm[lpos(base + r * m)] = x[r];
+    __syncthreads();
+  }
+  if (REM > 0) {
+    constexpr unsigned R = 1u << REM, G = 16 / R;
+#pragma unroll
+    for (unsigned j = 0; j < G; j++) {
+      const unsigned e0 = (t + j * T) * R;
+      u64 y[R];
+#pragma unroll
+      for (unsigned p = 0; p < R; p++) y[p] = sm[lpos(e0 + p)];
+      if (REM == 1) { u64 p0 = y[0], p1 = y[1]; y[0] = gl_add(p0, p1); y[1] = gl_sub(p0, p1); }
+      if (REM == 2) {
+        u64 a0 = gl_add(y[0], y[2]), a2 = gl_sub(y[0], y[2]), a1 = gl_add(y[1], y[3]), a3 = mulc(gl_sub(y[1], y[3]), a.w16.w[4]);
+        y[0] = gl_add(a0, a1); y[1] = gl_sub(a0, a1); y[2] = gl_add(a2, a3); y[3] = gl_sub(a2, a3);
+      }
+      if (REM == 3) {
+        u64 z[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { u64 p = y[k], q = y[k + 4]; z[k] = gl_add(p, q); u64 d = gl_sub(p, q); z[k + 4] = k ? mulc(d, a.w16.w[2 * k]) : d; }
+#pragma unroll
+        for (int h = 0; h < 8; h += 4)
+#pragma unroll
+          for (int k = 0; k < 2; k++) { u64 p = z[h + k], q = z[h + k + 2]; z[h + k] = gl_add(p, q); u64 d = gl_sub(p, q); z[h + k + 2] = k ? mulc(d, a.w16.w[4]) : d; }
+#pragma unroll
+        for (int p = 0; p < 8; p += 2) { u64 u0 = z[p], u1 = z[p + 1]; y[p] = gl_add(u0, u1); y[p + 1] = gl_sub(u0, u1); }
+      }
+#pragma unroll
+      for (unsigned p = 0; p < R; p++) sm[lpos(e0 + p)] = y[p];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const unsigned e = k * T + t;
+    const unsigned s_e = a.out_natural ? rev_bits(e, K) : e;
+    u64 v = sm[lpos(s_e)];
+    if (a.scale != 1) v = mulc(v, a.scale);
+    dst[e] = v;
+  }
+}
+
+template <int K> static void launch16(const Ntt16Args& a, int transforms, hipStream_t s) {
+  constexpr size_t lds = ((size_t(1) << K) + (size_t(1) << (K - 4))) * 8;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_ntt16<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL(k_ntt16<K>, dim3(1, (unsigned)transforms), dim3(1u << (K - 4)), lds, s, a);
+}
+
+bool ntt16_supported(int log_n) { return log_n >= 9 && log_n <= 14; }
+
+void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, bool inverse,
+               bool out_natural, const u64* pre, u64 scale, const NttPlan& pl, hipStream_t s) {
+  if (count <= 0) return;
+  Ntt16Args a; a.in = in; a.in_stride = in_stride; a.out = out; a.out_stride = out_stride; a.pre = pre; a.rt = pl.rt; a.log_M = pl.log_M;
+  a.scale = scale; a.log_cosets = log_cosets; a.inverse = inverse; a.out_natural = out_natural;
+  u64 w = gl_root(4); if (inverse) w = gl_inv(w);
+  u64 x = 1; for (int j = 0; j < 8; j++) { a.w16.w[j] = x; x = gl_mul(x, w); }
+  const int transforms = count << log_cosets;
+  switch (log_n) {
+    case 9: launch16<9>(a, transforms, s); break;
+    case 10: launch16<10>(a, transforms, s); break;
+    case 11: launch16<11>(a, transforms, s); break;
+    case 12: launch16<12>(a, transforms, s); break;
+    case 13: launch16<13>(a, transforms, s); break;
+    case 14: launch16<14>(a, transforms, s); break;
+    default: break;
+  }
+}
+
+} // namespace qp

@@ -183,6 +183,7 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
 // values [cols][n] (natural order) -> coefficients [cols][n]; `tmp` needs cols*n elements and is clobbered.
 static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
   ProfScope ps(w, s, PF_INTT, 8.0 * cols * c->n * 2);
+  if (ntt16_supported(c->log_n)) { ntt16_run(vals, c->n, coeffs, c->n, cols, c->log_n, 0, true, true, nullptr, gl_inv((u64)c->n), c->pl, s); return; }
   ntt_copy(vals, c->n, tmp, c->n, cols, c->log_n, false, true, c->pl, s);             // inverse DIF: bit-reversed, unscaled
   bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
 }
