@@ -104,6 +104,24 @@ int qpgpu_test_intt_natural(const uint64_t* vals, int count, int log_n, uint64_t
   return 0;
 }
 
+// PMC calibration kernel: streams a [width][n] column-major matrix with the leaf kernel's access pattern (8 B per lane per
+// column) and writes one u64 per row, so FETCH_SIZE / WRITE_SIZE can be scaled against a known byte count
+// (MI355X_MICROARCH.md: FETCH_SIZE is only calibrated for 16 B/lane streams).
+__global__ void __launch_bounds__(256) k_calib_colsum(const u64* cols, size_t stride, int width, size_t n, u64* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 acc = 0;
+  for (int k = 0; k < width; k++) acc ^= cols[(size_t)k * stride + i];
+  out[i] = acc;
+}
+int qpgpu_test_calib_colsum(int width, size_t n, int iters) {
+  DevBuf c, o; HOOK_CHECK(c.alloc((size_t)width * n * 8)); HOOK_CHECK(o.alloc(n * 8));
+  HOOK_CHECK(hipMemset(c.p, 3, (size_t)width * n * 8));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_calib_colsum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c.u(), n, width, n, o.u());
+  HOOK_CHECK(hipDeviceSynchronize());
+  return 0;
+}
+
 // Timing hook: ms per launch of the x8 coset LDE of `count` columns of 2^log_n coefficients (device-resident data).
 double qpgpu_bench_lde(int count, int log_n, int iters, int force_generic) {
   size_t n = size_t(1) << log_n, N = n << 3; int log_N = log_n + 3;
