@@ -22,6 +22,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def available_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives a share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -30,7 +42,8 @@ def main():
     ap.add_argument("--preset", default="B", help="A: leaf non-zk 2^13, B: leaf zk 2^14 (default), V: voting-shaped 2^20")
     ap.add_argument("--batch", type=int, default=1, help=">1: each step is one stream-pipelined batch (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-proofs", type=int, default=2)
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra (untimed-headline) stream-pipelined throughput measurement")
+    ap.add_argument("--cpu-proofs", type=int, default=8)
     args = ap.parse_args()
 
     import numpy as np
@@ -128,6 +141,36 @@ def main():
                     "note": "Poseidon leaf hashing is integer-VALU-bound, not HBM-bound (DESIGN.md §4); frac is still quoted against HBM peak",
                     "avg_launch_ms": round(kd["avg_ms"], 4), "alg_bytes_per_launch": kd["alg_bytes_per_launch"]}
 
+    # ---- extra, NOT the headline: stream-pipelined throughput of independent proofs on this GPU (BASELINE configs[2] style)
+    pipelined = None
+    if args.batch == 1 and not args.no_pipelined:
+        nb = 16
+        ptrs = [wit_dev[j % nwit].data_ptr() for j in range(nb)]
+        pl = [pis_list[j % nwit] for j in range(nb)]
+        gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)          # warm the per-stream workspaces
+        barrier(); t2 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)
+        barrier(); pdt = time.perf_counter() - t2
+        if dist is not None:
+            t = torch.tensor([pdt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); pdt = float(t.item())
+        pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
+                     "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
+
+    # Poseidon throughput of the dominant kernel against the measured VALU issue ceiling
+    valu = None
+    if "merkle_leaves_colmajor" in kernels:
+        d = sc.desc; s_ = 4 if d.zero_knowledge else 0
+        widths = [d.num_wires + s_, d.num_challenges * (1 + d.num_partial_products) + s_, d.num_challenges * d.quotient_degree_factor + s_]
+        perms = sum(-(-w // 8) for w in widths) * sc.N
+        tot_ms = kernels["merkle_leaves_colmajor"]["total_ms"] / (kernels["merkle_leaves_colmajor"]["launches"] / 3.0)
+        pps = perms / (tot_ms * 1e-3)
+        instr_per_perm = 26500.0
+        ceiling = 1024 * 2.4e9 / 4.3 * 64 / instr_per_perm          # SIMDs x clock / measured cycles per wave-instr x lanes / instr per permutation
+        valu = {"permutations_per_s": round(pps / 1e9, 3), "unit": "G perm/s", "instr_per_permutation": instr_per_perm,
+                "issue_ceiling_G_perm_per_s": round(ceiling / 1e9, 3), "frac": round(pps / ceiling, 3)}
+
     nproofs = args.steps * args.batch * world
     out = {
         "metric": "wormhole proofs/s", "value": round(nproofs / dt, 3), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
@@ -140,23 +183,23 @@ def main():
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
-        "roofline": roofline, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "roofline": roofline, "valu_roofline": valu, "pipelined": pipelined, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oc = H.OracleCircuit(sc.desc)
-        cores = H.oracle().orc_max_threads()
+        cores = min(available_cores(), H.oracle().orc_max_threads())
         w0, p0 = sc.witness(seeds[0])
         salts = sc.salts(seeds[0]) if sc.desc.zero_knowledge else None
-        oc.prove(w0, p0, salts)                      # warm (twiddle tables, page faults)
+        oc.prove(w0, p0, salts, threads=cores)       # warm (twiddle tables, page faults)
         t1 = time.perf_counter()
         for _ in range(args.cpu_proofs):
-            cpu_pf = oc.prove(w0, p0, salts)
+            cpu_pf = oc.prove(w0, p0, salts, threads=cores)
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(args.cpu_proofs / cdt, 4), "unit": "proofs/s", "cores": cores, "kind": "port",
                                "sample": "%d proofs of the same circuit/witness by oracle/ (C++ restatement of qp-plonky2's prover, OpenMP); "
-                                         "the Rust reference cannot be built here (no cargo, crates not on disk)" % args.cpu_proofs,
+                                         "threads = cgroup CPU share of the box; the Rust reference cannot be built here (no cargo, crates not on disk)" % args.cpu_proofs,
                                "ms_per_proof": round(cdt / args.cpu_proofs * 1e3, 2)}
         out["bit_exact_vs_cpu"] = bool(cpu_pf == gc.prove(None, p0, salt_seed=seeds[0], wires_dev_ptr=wit_dev[0].data_ptr()))
     if rank == 0:
