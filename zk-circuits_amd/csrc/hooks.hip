@@ -78,6 +78,33 @@ double qpgpu_test_host_permute_ns(int iters) {
   volatile u64 sink = st[0]; (void)sink;
   return std::chrono::duration<double, std::nano>(t1 - t0).count() / iters;
 }
+double qpgpu_test_sync_roundtrip_us2(int iters, int mode) {
+  // mode 0: hipStreamSynchronize; 1: spin on hipStreamQuery; 2: spin on hipEventQuery; 3: kernel writes pinned host memory, host spins on it
+  if (mode == 10) { return (double)hipSetDeviceFlags(hipDeviceScheduleSpin); }
+  DevBuf d; if (d.alloc(4096) != hipSuccess) return -1;
+  u64* pin = nullptr; if (hipHostMalloc((void**)&pin, 4096, hipHostMallocMapped) != hipSuccess) return -1;
+  u64* pin_dev = nullptr; (void)hipHostGetDevicePointer((void**)&pin_dev, pin, 0);
+  hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  salt_fill(d.u(), 16, 1, 0, s); (void)hipStreamSynchronize(s);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) {
+    if (mode == 3) {
+      volatile u64* flag = pin + 64; *flag = 0;
+      salt_fill(pin_dev, 17, (u64)i + 1, 0, s);            // writes 68 u64 incl. slot 64 (non-zero with overwhelming probability)
+      while (*flag == 0) { }
+    } else {
+      salt_fill(d.u(), 16, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s);
+      if (mode == 0) (void)hipStreamSynchronize(s);
+      else if (mode == 1) { while (hipStreamQuery(s) == hipErrorNotReady) { } }
+      else { (void)hipEventRecord(ev, s); while (hipEventQuery(ev) == hipErrorNotReady) { } }
+    }
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  (void)hipStreamSynchronize(s);
+  (void)hipEventDestroy(ev); (void)hipStreamDestroy(s); (void)hipHostFree(pin);
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+}
 double qpgpu_test_sync_roundtrip_us(int iters) {
   DevBuf d; if (d.alloc(4096) != hipSuccess) return -1;
   u64* pin = nullptr; if (hipHostMalloc((void**)&pin, 4096, hipHostMallocDefault) != hipSuccess) return -1;
@@ -120,6 +147,18 @@ int qpgpu_test_calib_colsum(int width, size_t n, int iters) {
   for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_calib_colsum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c.u(), n, width, n, o.u());
   HOOK_CHECK(hipDeviceSynchronize());
   return 0;
+}
+
+// Timing hook: G permutations/s of the one-permutation-per-lane kernel at a given grid size (occupancy sweep)
+double qpgpu_bench_permute(size_t count, int iters) {
+  DevBuf d; if (d.alloc(count * 96) != hipSuccess) return -1;
+  (void)hipMemset(d.p, 0, count * 96);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  poseidon_permute_batch(d.u(), count, 0); (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0); for (int i = 0; i < iters; i++) poseidon_permute_batch(d.u(), count, 0); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (double)count * iters / (ms * 1e-3) / 1e9;
 }
 
 // Timing hook: ms per launch of the x8 coset LDE of `count` columns of 2^log_n coefficients (device-resident data).

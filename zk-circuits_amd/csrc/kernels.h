@@ -38,6 +38,10 @@ void bitrev_permute(const u64* in, size_t in_stride, u64* out, size_t out_stride
 bool ntt16_supported(int log_n);
 void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, bool inverse,
                bool out_natural, const u64* pre, u64 scale, const NttPlan& pl, hipStream_t s);
+// Device -> host hand-off without a copy engine round trip: a kernel copies `words` u64 from device memory into mapped pinned
+// host memory, fences at system scope and then stores `seq` into *flag (also pinned); the host spins on the flag.
+// Measured 7.5 us per hand-off versus 15.2 us for hipMemcpyAsync + hipStreamSynchronize (tools/ubench notes in DESIGN.md).
+void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s);
 // cols[k][L] = salt_value(seed, (oracle*4 + k)*N + L) for k < 4 (salt.h)
 void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
 

@@ -15,6 +15,25 @@ void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s) {
   hipLaunchKernelGGL(k_salt_fill, dim3((unsigned)((4 * N + 255) / 256)), dim3(256), 0, s, cols, N, seed, oracle);
 }
 
+__global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (gridDim.x > 1) {
+      unsigned long long prev = atomicAdd((unsigned long long*)counter, 1ULL);
+      last = prev + 1 == gridDim.x;
+      if (last) *counter = 0;                     // publishes on one workspace are stream-ordered, so the reset cannot race
+    }
+    if (last) { __threadfence_system(); *(volatile u64*)flag = seq; }
+  }
+}
+void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s) {
+  unsigned blocks = (unsigned)((words + 2047) / 2048); if (blocks < 1) blocks = 1; if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq);
+}
+
 __global__ void k_permute_batch(u64* states, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(256) k_leaves_fri(const u64* a, const u64* b, 
 }
 // cooperative form: 16 lanes per leaf (layers have few leaves, each a short sponge)
 __global__ void __launch_bounds__(64) k_leaves_fri_coop(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests) {
-  __shared__ u64 xch[4][12];
+  __shared__ u64 xch[4][24];
   const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
   const size_t L = (size_t)blockIdx.x * 4 + g, LL = L < num_leaves ? L : num_leaves - 1;
   CoopCtx cx; coop_init(cx, i);
@@ -164,7 +183,7 @@ __global__ void __launch_bounds__(256) k_level_lane(const u64* in, u64* out, siz
   for (int k = 0; k < 4; k++) out[p * 4 + k] = st[k];
 }
 __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size_t parents) {
-  __shared__ u64 xch[4][12];
+  __shared__ u64 xch[4][24];
   const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
   const size_t p = (size_t)blockIdx.x * 4 + g;
   CoopCtx cx; coop_init(cx, i);

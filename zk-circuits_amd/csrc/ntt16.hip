@@ -11,6 +11,7 @@
 // the tiled multi-pass kernel in ntt.hip. Rows a3/a4 of SURVEY.md §8.
 #include "kernels.h"
 #include "poseidon_dev.h"
+#include <cstdlib>
 
 namespace qp {
 
@@ -134,7 +135,15 @@ template <int K> static void launch16(const Ntt16Args& a, int transforms, hipStr
   hipLaunchKernelGGL(k_ntt16<K>, dim3(1, (unsigned)transforms), dim3(1u << (K - 4)), lds, s, a);
 }
 
-bool ntt16_supported(int log_n) { return log_n >= 9 && log_n <= 14; }
+bool ntt16_supported(int log_n) {
+  static const int disabled = [] { const char* v = getenv("QPGPU_NTT16"); return v && v[0] == '0'; }();   // A/B switch for experiments
+  // Measured on MI355X (profiles/r01 notes): at 2^13/2^14 the 64-139 KB LDS image allows one or two workgroups per CU, which
+  // gains nothing for a single proof (5.18 vs 5.14 ms) and costs 12 % of stream-pipelined throughput (240 vs 273 proofs/s)
+  // because it evicts co-resident kernels of other proofs. Up to 2^12 (35 KB, 256 threads) it is 1.6-1.8x faster than the
+  // tiled kernel, so that is where it is used (FRI layers, small circuits); QPGPU_NTT16=2 forces it up to 2^14.
+  static const int force = [] { const char* v = getenv("QPGPU_NTT16"); return v && v[0] == '2'; }();
+  return !disabled && log_n >= 9 && log_n <= (force ? 14 : 12);
+}
 
 void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, bool inverse,
                bool out_natural, const u64* pre, u64 scale, const NttPlan& pl, hipStream_t s) {

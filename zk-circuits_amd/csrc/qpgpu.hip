@@ -59,6 +59,9 @@ static constexpr int PROF_EVENTS = 128;
 struct Workspace {
   hipEvent_t pev[PROF_EVENTS]; int pev_made = 0, pev_used = 0; int pev_id[PROF_EVENTS / 2]; double pev_bytes[PROF_EVENTS / 2];
   DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
+  u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
+  u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
+  u64 pub_seq = 0;
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
   u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
@@ -86,7 +89,8 @@ struct qpgpu_circuit {
 struct ProfScope {   // records an event pair around the launches made inside its lifetime
   Workspace* w; hipStream_t s; bool on;
   ProfScope(Workspace* w_, hipStream_t s_, int id, double bytes) : w(w_), s(s_), on(false) {
-    if (!g_prof_on.load(std::memory_order_relaxed) || w->pev_used + 2 > PROF_EVENTS) return;
+    const int mode = g_prof_on.load(std::memory_order_relaxed);       // 0 off, 1 leaf-hash group only (cheap enough for timed runs), 2 all groups
+    if (!mode || (mode == 1 && id != PF_LEAVES) || w->pev_used + 2 > PROF_EVENTS) return;
     while (w->pev_made < w->pev_used + 2) { if (hipEventCreate(&w->pev[w->pev_made]) != hipSuccess) return; w->pev_made++; }
     on = true; w->pev_id[w->pev_used / 2] = id; w->pev_bytes[w->pev_used / 2] = bytes;
     (void)hipEventRecord(w->pev[w->pev_used], s);
@@ -120,7 +124,7 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   w->openings = a.take(2 * c->lay.n_openings);
   w->open_partial = a.take(2 * (size_t)(c->S + c->W) * open_chunks(c->log_n));
   w->compose_partial = a.take((size_t)FRI_COMPOSE_GROUPS * 2 * n);
-  w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n); w->pow_result = a.take(4);
+  w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n); w->pow_result = a.take(4); w->pub_counter = a.take(4);
   for (int l = 0; l <= c->nlayers; l++) w->fri_coeffs[l] = a.take((size_t)2 << c->fri_log_n[l]);
   for (int l = 0; l < c->nlayers; l++) {
     size_t Nl = (size_t)1 << (c->fri_log_n[l] + c->rate);
@@ -145,8 +149,11 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
   e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_HIP, "hipStreamCreate failed"); }
   w->pinned_elems = 4096 + 2 * c->lay.n_openings + (c->lay.bytes_per_query * c->d.fri_num_queries) / 8 + 64;
-  e = hipHostMalloc((void**)&w->pinned, w->pinned_elems * 8, hipHostMallocDefault);
+  e = hipHostMalloc((void**)&w->pinned, (w->pinned_elems + 8) * 8, hipHostMallocMapped);
   if (e != hipSuccess) { (void)hipStreamDestroy(w->stream); (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_OOM, "hipHostMalloc failed"); }
+  if (hipHostGetDevicePointer((void**)&w->pinned_dev, w->pinned, 0) != hipSuccess) w->pinned_dev = nullptr;
+  w->pinned[w->pinned_elems] = 0;
+  (void)hipMemsetAsync(w->pub_counter, 0, 8, w->stream);
   *out = w; return 0;
 }
 static void ws_release(qpgpu_circuit* c, Workspace* w) { std::lock_guard<std::mutex> lk(c->mu); c->free_ws.push_back(w); }
@@ -157,6 +164,30 @@ static void ws_destroy(Workspace* w) {
   if (w->stream) (void)hipStreamDestroy(w->stream);
   if (w->arena.base) (void)hipFree(w->arena.base);
   delete w;
+}
+
+// Brings `words` u64 from device memory to w->pinned and waits for them. Fast path: publish kernel + spin on the mapped flag;
+// fallback (no mapped pointer, or the flag does not arrive): copy + stream synchronise, which also surfaces kernel faults.
+static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t words) {
+  if (w->pinned_dev && getenv_int("QPGPU_NO_PUBLISH", 0) == 0) {
+    const u64 seq = ++w->pub_seq;
+    volatile u64* flag = w->pinned + w->pinned_elems;
+    publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s);
+    for (uint64_t spins = 0;; spins++) {
+      if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 0xFFFFF) == 0xFFFFF) {          // ~ every few ms: has the stream died?
+        hipError_t q = hipStreamQuery(s);
+        if (q != hipSuccess && q != hipErrorNotReady) return set_err(QPGPU_ERR_HIP, std::string("stream error while waiting: ") + hipGetErrorString(q));
+        if (q == hipSuccess && *flag != seq && spins > (1ULL << 26)) break;   // kernel finished but flag never arrived: fall back
+      }
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(w->pinned, src, words * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
 }
 
 // Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
@@ -177,8 +208,10 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
     merkle_levels(dig, N, c->cap_h, s, done); }
-  size_t cap_off = merkle_total_digests(N, c->cap_h) - (size_t(1) << c->cap_h);
-  if (cap_host) (void)hipMemcpyAsync(cap_host, dig + cap_off * 4, (size_t(32)) << c->cap_h, hipMemcpyDeviceToHost, s);
+  (void)cap_host;
+}
+static const u64* cap_ptr(qpgpu_circuit* c, const u64* dig, size_t leaves) {
+  return dig + (merkle_total_digests(leaves, c->cap_h) - (size_t(1) << c->cap_h)) * 4;
 }
 // values [cols][n] (natural order) -> coefficients [cols][n]; `tmp` needs cols*n elements and is clobbered.
 static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
@@ -347,7 +380,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
   commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, opts, salt_seed, salts_host, pin, s);
-  HIP_TRY(hipStreamSynchronize(s));
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out, pin, L.cap_bytes);
   Challenger ch;
@@ -360,7 +393,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
   values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
   commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, opts, salt_seed, salts_host, pin, s);
-  HIP_TRY(hipStreamSynchronize(s));
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->zs_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + L.cap_bytes, pin, L.cap_bytes);
   ch.observe_n(pin, capn * 4);
@@ -373,7 +406,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
   commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, opts, salt_seed, salts_host, pin, s);
-  HIP_TRY(hipStreamSynchronize(s));
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
   ch.observe_n(pin, capn * 4);
@@ -402,8 +435,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, w->open_partial, o, s);
   }
   delete pso;
-  HIP_TRY(hipMemcpyAsync(pin, w->openings, 16 * L.n_openings, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { int rc_ = fetch_to_host(w, s, w->openings, 2 * L.n_openings); if (rc_) return rc_; }
   mark();
   memcpy(out + L.openings_off, pin, 16 * L.n_openings);
   {
@@ -427,10 +459,8 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const size_t leaves = Nl >> c->arity[l];
     merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
     merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
-    size_t cap_off = merkle_total_digests(leaves, c->cap_h) - capn;
     delete psl;
-    HIP_TRY(hipMemcpyAsync(pin, w->fri_dig[l] + cap_off * 4, L.cap_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->fri_dig[l], leaves), capn * 4); if (rc_) return rc_; }
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
     ch.observe_n(pin, capn * 4);
     fri_betas[l] = ch.challenge_ext();
@@ -439,8 +469,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   }
   {
     const size_t fl = L.final_poly_len;
-    HIP_TRY(hipMemcpyAsync(pin, w->fri_coeffs[c->nlayers], 2 * fl * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    { int rc_ = fetch_to_host(w, s, w->fri_coeffs[c->nlayers], 2 * fl); if (rc_) return rc_; }
     u64* fp = (u64*)(out + L.final_poly_off);
     for (size_t i = 0; i < fl; i++) { u64 a = pin[i], b = pin[fl + i]; memcpy(&fp[2 * i], &a, 8); memcpy(&fp[2 * i + 1], &b, 8); ch.observe(a); ch.observe(b); }
   }
@@ -457,8 +486,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     u64 base = 0, span = 1ULL << 17;
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
-      HIP_TRY(hipMemcpyAsync(pin, w->pow_result, 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      { int rc_ = fetch_to_host(w, s, w->pow_result, 1); if (rc_) return rc_; }
       pow_witness = pin[0]; base += span; if (span < (1ULL << 26)) span <<= 1;
     }
     if (pow_witness == none) return set_err(QPGPU_ERR_POW, "proof-of-work grind found no witness");
@@ -485,12 +513,12 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query;
   for (int q = 0; q < ga.nq; q++) ga.idx[q] = (u32)(ch.challenge() % N);
   { ProfScope ps(w, s, PF_GATHER, 2.0 * L.bytes_per_query * ga.nq); query_gather(ga, w->query_bytes, s); }
-  HIP_TRY(hipMemcpyAsync(pin, w->query_bytes, L.bytes_per_query * ga.nq, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { int rc_ = fetch_to_host(w, s, (const u64*)w->query_bytes, (L.bytes_per_query * ga.nq + 7) / 8); if (rc_) return rc_; }
   HIP_TRY(hipGetLastError());
   memcpy(out + L.queries_off, pin, L.bytes_per_query * ga.nq);
   { u64 npi = d.num_public_inputs; memcpy(out + L.pis_off, &npi, 8); memcpy(out + L.pis_off + 8, pis, 8 * npi); }
   mark();
+  if (w->pev_used || timing) HIP_TRY(hipStreamSynchronize(s));     // event timestamps need the stream drained (the hand-offs above do not sync)
   prof_flush(w);
   if (timing) {
     g_stage_n = nev - 1;
