@@ -57,7 +57,7 @@ def main():
         if rank == 0:
             print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("QP_BENCH_FORCE_DIST"):      # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "poseidon_dev.h"
 #include "salt.h"
+#include <cstdlib>
 
 namespace qp {
 
@@ -53,6 +54,7 @@ void poseidon_permute_batch(u64* states, size_t count, hipStream_t s) {
 // cost is pure permutation latency. It only pays when the grid is several times larger than what is resident at once
 // (measured on MI355X: at N = 2^17 all 512 blocks run in lockstep, so the fused tail costs two more permutation
 // latencies at half/quarter occupancy and the leaf+levels total gets 5 % WORSE; profiles/r01 notes). Enabled from 2^20 leaves.
+static constexpr size_t PAIR_MAX_LEAVES = size_t(1) << 18;   // <= 4 waves/SIMD per-lane: the pair form fills the chip better
 template <bool FUSE>
 __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
                                                          u64* level1, u64* level2) {
@@ -112,6 +114,47 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
     }
   }
 }
+// Pair form: two lanes per leaf (poseidon_dev.h). Used when the tree has too few leaves to fill the chip one-per-lane.
+__global__ void __launch_bounds__(256) k_leaves_colmajor_pair(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests) {
+  const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int p = (int)(gid & 1);
+  size_t L = gid >> 1; const bool live = L < num_leaves; if (!live) L = num_leaves - 1;     // keep whole waves converged
+  PairCtx cx; pair_init(cx, p);
+  u64 own[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) own[j] = 0;
+  if (width <= 4) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) if (2 * j + p < width) own[j] = cols[(size_t)(2 * j + p) * col_stride + L];
+  } else {
+    for (int off = 0; off < width; off += 8) {
+      const int m = width - off < 8 ? width - off : 8;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (2 * j + p < m) own[j] = cols[(size_t)(off + 2 * j + p) * col_stride + L];
+      poseidon_permute_pair(own, cx);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) digests[L * 4 + 2 * j + p] = own[j];
+  }
+}
+__global__ void __launch_bounds__(256) k_level_pair(const u64* in, u64* out, size_t parents) {
+  const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int p = (int)(gid & 1);
+  size_t node = gid >> 1; const bool live = node < parents; if (!live) node = parents - 1;
+  PairCtx cx; pair_init(cx, p);
+  u64 own[6];
+#pragma unroll
+  for (int j = 0; j < 4; j++) own[j] = in[node * 8 + 2 * j + p];
+  own[4] = 0; own[5] = 0;
+  poseidon_permute_pair(own, cx);
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) out[node * 4 + 2 * j + p] = own[j];
+  }
+}
+
 // Returns the number of tree levels already produced above the leaves (0 or 2).
 int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s) {
   const bool fuse = (num_leaves % 256 == 0) && (num_leaves >> 2) >= (size_t(1) << cap_height) && num_leaves >= (size_t(1) << 20);
@@ -120,6 +163,14 @@ int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t
     hipLaunchKernelGGL(k_leaves_colmajor<true>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4,
                        digests + (num_leaves + num_leaves / 2) * 4);
     return 2;
+  }
+  // Measured (MI355X, 2^17 leaves): the pair form hashes leaves 9 % SLOWER than one permutation per lane (its per-lane stream is
+  // not half: DPP moves, parity-selected constants and the one-sided partial rounds add ~20 % work), so it is only used for the
+  // latency-bound tree levels below; QPGPU_PAIR_LEAVES=1 switches it on here for experiments.
+  static const bool pair_leaves = [] { const char* v = getenv("QPGPU_PAIR_LEAVES"); return v && v[0] == '1'; }();
+  if (pair_leaves && num_leaves <= PAIR_MAX_LEAVES && num_leaves >= 2) {
+    hipLaunchKernelGGL(k_leaves_colmajor_pair, dim3((unsigned)((2 * num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
+    return 0;
   }
   hipLaunchKernelGGL(k_leaves_colmajor<false>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
   return 0;
@@ -198,7 +249,8 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
   for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {
     size_t parents = cnt >> 1; u64* out = cur + cnt * 4;
-    if (parents > COOP_MAX_PARENTS) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
+    if (parents > PAIR_MAX_LEAVES) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
+    else if (parents > COOP_MAX_PARENTS) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
     else hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, cur, out, parents);
     cur = out; cnt = parents;
   }

@@ -17,13 +17,12 @@ __device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + 
 // lo + 2^64*hi  ->  lazy residue (any u64 congruent mod p)
 __device__ __forceinline__ u64 red128_lazy(u64 lo, u64 hi) {
   const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
-  u64 t0 = lo - h1;
-  const u32 bm = lo < (u64)h1 ? 0xFFFFFFFFu : 0u;       // wrapped by 2^64: owe -(2^32-1)
-  u64 u = (u64)h0 * 0xFFFFFFFFu;                         // h0 * (2^32-1) < 2^64
-  u64 t2 = t0 + u;
-  const u32 cm = t2 < u ? 0xFFFFFFFFu : 0u;             // wrapped: owe +(2^32-1)
-  // t2 + cm - bm (as 64-bit quantities 0 or 2^32-1); cannot wrap again
-  return t2 + (u64)cm - (u64)bm;
+  unsigned long long t0;
+  const bool b = __builtin_usubll_overflow((unsigned long long)lo, (unsigned long long)h1, &t0);   // wrapped by 2^64: owe -(2^32-1)
+  const u64 t2 = mad32(h0, 0xFFFFFFFFu, (u64)t0);                                                  // + h0 * (2^32-1), one v_mad_u64_u32
+  const bool c = t2 < (u64)t0;                                                                     // wrapped: owe +(2^32-1)
+  // t2 + (c - b)(2^32-1) in wrapping arithmetic; cannot wrap again
+  return t2 + ((c ? GL_EPS : 0) - (b ? GL_EPS : 0));
 }
 __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -129,6 +128,72 @@ __device__ __forceinline__ void poseidon_permute_dev(u64 st[12]) {
   mds_rc_lazy(st, nullptr);
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair permutation: two adjacent lanes (2k, 2k+1) share one state; the lane with parity p holds elements 2j+p, j < 6.
+// Total instruction work equals the one-permutation-per-lane form (each lane runs 6 S-boxes and 6 MDS rows; the other
+// half of every row's inputs arrives through twelve quad_perm DPP moves), but a stage gets twice the waves, which is what
+// the single-proof case lacks: leaf hashing of 2^17 leaves is only 2 waves/SIMD per-lane (1.43 G perm/s) versus 4 waves
+// as pairs (1.58 G perm/s measured for the per-lane kernel at that occupancy), and tree levels 1-2 halve their latency.
+struct PairCtx { u32 co[6]; u32 d0; int p; };
+__device__ __forceinline__ void pair_init(PairCtx& cx, int p) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+#pragma unroll
+  for (int d = 0; d < 6; d++) cx.co[d] = p ? C[(2 * d + 11) % 12] : C[2 * d + 1];   // multiplier of the partner's element j' for row j, d = (j'-j) mod 6
+  cx.d0 = p ? 0u : 8u; cx.p = p;
+}
+__device__ __forceinline__ u32 dpp_swap_pair(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false); }
+// own[j] = element 2j+p (lazy in, lazy out); next-round constants rcn (uniform pointer to 12 values) or null
+__device__ __forceinline__ void pair_mds_rc(u64 own[6], const PairCtx& cx, const u64* __restrict__ rcn) {
+  const u32 CE[6] = {17, 41, 2, 13, 39, 34};      // C[2d]: multiplier of own element j' for row j, d = (j'-j) mod 6
+  u32 lo[6], hi[6], olo[6], ohi[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) { lo[j] = (u32)own[j]; hi[j] = (u32)(own[j] >> 32); olo[j] = dpp_swap_pair(lo[j]); ohi[j] = dpp_swap_pair(hi[j]); }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    u64 c = 0;
+    if (rcn) { u64 c0 = rcn[2 * j], c1 = rcn[2 * j + 1]; c = cx.p ? c1 : c0; }
+    u64 sl = (u32)c, sh = c >> 32;
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++) {
+      const int d = (jj - j + 6) % 6;
+      sl = mad32(lo[jj], CE[d], sl); sh = mad32(hi[jj], CE[d], sh);
+      sl = mad32(olo[jj], cx.co[d], sl); sh = mad32(ohi[jj], cx.co[d], sh);
+    }
+    if (j == 0) { sl = mad32(lo[0], cx.d0, sl); sh = mad32(hi[0], cx.d0, sh); }
+    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
+    u64 add = (u64)(u32)sh << 32;
+    u64 v = t + add;
+    if (v < add) v += GL_EPS;
+    own[j] = v;
+  }
+}
+// Both lanes of a pair must call this together (whole waves: never under divergent control flow). Output canonical.
+__device__ __forceinline__ void poseidon_permute_pair(u64 own[6], const PairCtx& cx) {
+  const u64* rc = POSEIDON_RC_DEV;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { u64 c0 = rc[2 * j], c1 = rc[2 * j + 1]; own[j] = add_lazy_canon(own[j], cx.p ? c1 : c0); }
+  int r = 0;
+  for (; r < 4; r++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) own[j] = sbox7_lazy(own[j]);
+    pair_mds_rc(own, cx, rc + 12 * (r + 1));
+  }
+  for (; r < 26; r++) {
+    if (cx.p == 0) own[0] = sbox7_lazy(own[0]);
+    pair_mds_rc(own, cx, rc + 12 * (r + 1));
+  }
+  for (; r < 29; r++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) own[j] = sbox7_lazy(own[j]);
+    pair_mds_rc(own, cx, rc + 12 * (r + 1));
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) own[j] = sbox7_lazy(own[j]);
+  pair_mds_rc(own, cx, nullptr);
+#pragma unroll
+  for (int j = 0; j < 6; j++) own[j] = canon(own[j]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
