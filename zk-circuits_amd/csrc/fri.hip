@@ -60,33 +60,51 @@ __global__ void __launch_bounds__(256) k_div_prep(const u64* comp0, const u64* c
   Ext t1 = ex_mul(ex(comp1[i], comp1[n + i]), ex(zp1_a[i], zp1_b[i]));
   scratch[i] = t0.a; scratch[n + i] = t0.b; scratch[2 * n + i] = t1.a; scratch[3 * n + i] = t1.b;
 }
-// exclusive suffix sum in place: arr[k] = sum_{i>k} arr[i]; one block per array
-__global__ void __launch_bounds__(1024) k_suffix_sum(u64* arrs, size_t n) {
-  __shared__ u64 sm[1024];
-  u64* t = arrs + (size_t)blockIdx.x * n;
-  const size_t seg = (n + 1023) / 1024;
-  // thread r owns the r-th segment counted from the END
-  const size_t hi = n > (size_t)threadIdx.x * seg ? n - (size_t)threadIdx.x * seg : 0;
-  const size_t lo = hi > seg ? hi - seg : 0;
-  u64 acc = 0;
-  for (size_t i = lo; i < hi; i++) acc = gl_add(acc, t[i]);
+// Exclusive suffix sums, blocked: k_suffix_local leaves block-local suffix sums in place plus one total per block;
+// k_div_finish adds the totals of all later blocks while it applies z^-(k+1) and combines the two batches.
+static constexpr int SUF_BLOCK = 2048;
+__global__ void __launch_bounds__(256) k_suffix_local(u64* arrs, size_t n, u64* btot) {
+  __shared__ u64 sm[256];
+  u64* t = arrs + (size_t)blockIdx.y * n;
+  // thread r owns 8 consecutive elements; thread 0 owns the LAST 8 of the block (suffix direction)
+  const size_t blk_hi = (size_t)(blockIdx.x + 1) * SUF_BLOCK < n ? (size_t)(blockIdx.x + 1) * SUF_BLOCK : n;
+  const size_t blk_lo = (size_t)blockIdx.x * SUF_BLOCK;
+  const size_t hi = blk_hi > (size_t)threadIdx.x * 8 + blk_lo ? blk_hi - (size_t)threadIdx.x * 8 : blk_lo;
+  const size_t lo = hi > blk_lo + 8 ? hi - 8 : blk_lo;
+  u64 v[8]; u64 acc = 0; int cnt = (int)(hi - lo);
+  for (int r = 0; r < cnt; r++) { v[r] = t[lo + r]; acc = gl_add(acc, v[r]); }
   sm[threadIdx.x] = acc;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    u64 v = threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+  for (int off = 1; off < 256; off <<= 1) {
+    u64 x = threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
     __syncthreads();
-    sm[threadIdx.x] = gl_add(sm[threadIdx.x], v);
+    sm[threadIdx.x] = gl_add(sm[threadIdx.x], x);
     __syncthreads();
   }
-  u64 run = threadIdx.x ? sm[threadIdx.x - 1] : 0;   // sum of everything after this segment
-  for (size_t i = hi; i-- > lo;) { u64 v = t[i]; t[i] = run; run = gl_add(run, v); }
+  u64 run = threadIdx.x ? sm[threadIdx.x - 1] : 0;
+  for (int r = cnt - 1; r >= 0; r--) { t[lo + r] = run; run = gl_add(run, v[r]); }
+  if (threadIdx.x == 255) btot[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sm[255];
 }
-__global__ void __launch_bounds__(256) k_div_finish(const u64* scratch, size_t n, const u64* zi0_a, const u64* zi0_b, const u64* zi1_a,
-                                                    const u64* zi1_b, Ext alpha_shift, u64* final_ab) {
+__global__ void __launch_bounds__(256) k_div_finish(const u64* scratch, size_t n, const u64* btot, int nblk, const u64* zi0_a, const u64* zi0_b,
+                                                    const u64* zi1_a, const u64* zi1_b, Ext alpha_shift, u64* final_ab) {
+  __shared__ u64 sm[4][256];
+  const int blk = blockIdx.x / (SUF_BLOCK / 256);             // which scan block this thread block's 256 elements belong to
+  for (int a = 0; a < 4; a++) {                               // sum of the totals of all later blocks, per array
+    u64 acc = 0;
+    for (int b = blk + 1 + threadIdx.x; b < nblk; b += 256) acc = gl_add(acc, btot[(size_t)a * nblk + b]);
+    sm[a][threadIdx.x] = acc;
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) for (int a = 0; a < 4; a++) sm[a][threadIdx.x] = gl_add(sm[a][threadIdx.x], sm[a][threadIdx.x + off]);
+    __syncthreads();
+  }
   size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (k >= n) return;
-  Ext q0 = ex_mul(ex(scratch[k], scratch[n + k]), ex(zi0_a[k + 1], zi0_b[k + 1]));
-  Ext q1 = ex_mul(ex(scratch[2 * n + k], scratch[3 * n + k]), ex(zi1_a[k + 1], zi1_b[k + 1]));
+  Ext s0 = ex(gl_add(scratch[k], sm[0][0]), gl_add(scratch[n + k], sm[1][0]));
+  Ext s1 = ex(gl_add(scratch[2 * n + k], sm[2][0]), gl_add(scratch[3 * n + k], sm[3][0]));
+  Ext q0 = ex_mul(s0, ex(zi0_a[k + 1], zi0_b[k + 1]));
+  Ext q1 = ex_mul(s1, ex(zi1_a[k + 1], zi1_b[k + 1]));
   Ext f = ex_add(ex_mul(q0, alpha_shift), q1);
   final_ab[k] = f.a; final_ab[n + k] = f.b;
 }
@@ -94,9 +112,11 @@ void fri_divide_combine(const u64* comp0, const u64* comp1, int log_n, const u64
                         const u64* zp1_b, const u64* zi0_a, const u64* zi0_b, const u64* zi1_a, const u64* zi1_b, Ext alpha_shift,
                         u64* scratch, u64* final_ab, hipStream_t s) {
   size_t n = size_t(1) << log_n; unsigned blocks = (unsigned)((n + 255) / 256);
+  const unsigned nblk = (unsigned)((n + SUF_BLOCK - 1) / SUF_BLOCK);
+  u64* btot = scratch + 4 * n;
   hipLaunchKernelGGL(k_div_prep, dim3(blocks), dim3(256), 0, s, comp0, comp1, n, zp0_a, zp0_b, zp1_a, zp1_b, scratch);
-  hipLaunchKernelGGL(k_suffix_sum, dim3(4), dim3(1024), 0, s, scratch, n);
-  hipLaunchKernelGGL(k_div_finish, dim3(blocks), dim3(256), 0, s, scratch, n, zi0_a, zi0_b, zi1_a, zi1_b, alpha_shift, final_ab);
+  hipLaunchKernelGGL(k_suffix_local, dim3(nblk, 4), dim3(256), 0, s, scratch, n, btot);
+  hipLaunchKernelGGL(k_div_finish, dim3(blocks), dim3(256), 0, s, scratch, n, btot, (int)nblk, zi0_a, zi0_b, zi1_a, zi1_b, alpha_shift, final_ab);
 }
 
 // ---- fold

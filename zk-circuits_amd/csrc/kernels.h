@@ -79,10 +79,10 @@ struct CircuitDev {            // passed by value to kernels
 struct Chal2 { u64 v[2]; };
 
 // Z / partial products (row a7). wires_vals [W][n], sigma_vals [R][n] (values on the subgroup), out zpp_vals [nch*(1+npp)][n]
-// ordered [Z_0..Z_{nch-1}, pp_0(npp), pp_1(npp)...]. scratch: q [nch][n][npp+1] + totals [nch][n].
+// ordered [Z_0..Z_{nch-1}, pp_0(npp), pp_1(npp)...]. scratch: q [nch][n][npp+1] + local prefixes [nch][n] + block totals.
 void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_vals, Chal2 betas, Chal2 gammas, u64* scratch,
                  u64* zpp_vals, const NttPlan& pl, hipStream_t s);
-static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2); }
+static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2) + (size_t)nch * (n / 2048 + 2); }
 
 // alpha power table: out[c][i] = alpha_c^i, i < count
 void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
@@ -107,7 +107,7 @@ struct PolyGroup { const u64* base; size_t stride; int count; };
 static constexpr int FRI_COMPOSE_GROUPS = 8;
 void fri_compose(PolyGroup g0, PolyGroup g1, PolyGroup g2, PolyGroup g3, int nch, int log_n, Ext alpha, u64* partial, u64* comp0, u64* comp1, hipStream_t s);
 // final[k] = alpha^nch * Q0[k] + Q1[k], Q_b = (comp_b(X) - comp_b(z_b)) / (X - z_b); tables: zp_b = z_b^i, zi_b = z_b^{-i} (i <= n).
-// scratch: 4*n u64. final: [2][n].
+// scratch: 4*n + 4*(n/2048 + 1) u64. final: [2][n].
 void fri_divide_combine(const u64* comp0, const u64* comp1, int log_n, const u64* zp0_a, const u64* zp0_b, const u64* zp1_a,
                         const u64* zp1_b, const u64* zi0_a, const u64* zi0_b, const u64* zi1_a, const u64* zi1_b, Ext alpha_shift,
                         u64* scratch, u64* final_ab, hipStream_t s);

@@ -15,79 +15,129 @@ __device__ __forceinline__ u64 root_pow_d(const u64* rt, int log_M, u64 e) {
 }
 
 // ------------------------------------------------------------------ Z / partial products
+// 1. k_zpp_chunks: one thread per (4 rows, chunk of `qdf` routed wires, challenge): numerator / denominator products and one
+//    shared inversion (Montgomery trick over the 4 rows) -> chunk quotients q[c][row][chunk].
+// 2. k_zpp_scan_local: blocks of 2048 rows: row totals, block-local exclusive prefix products, block totals.
+// 3. k_zpp_finish: every block multiplies in the product of the preceding block totals (<= 512 of them) and writes Z and
+//    the running partial products. No single-block pass: the old one-block scan was 34 us of strided 8-byte loads.
 static constexpr int MAX_CHUNKS = 16;
+static constexpr int ZPP_ROWS_PER_THREAD = 4;
+static constexpr int SCAN_BLOCK = 2048;     // rows per scan block (256 threads x 8)
 
-__global__ void __launch_bounds__(256) k_zpp_rows(CircuitDev cd, const u64* wires, const u64* sigmas, Chal2 betas, Chal2 gammas,
-                                                  u64* q, u64* totals, const u64* rt, int log_M) {
-  const size_t n = size_t(1) << cd.log_n;
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = blockIdx.y, nchunks = cd.num_pp + 1, deg = cd.qdf;
+__global__ void __launch_bounds__(256) k_zpp_chunks(CircuitDev cd, const u64* __restrict__ wires, const u64* __restrict__ sigmas, Chal2 betas,
+                                                    Chal2 gammas, u64* __restrict__ q, const u64* __restrict__ rt, int log_M) {
+  const size_t n = size_t(1) << cd.log_n, quarter = n / ZPP_ROWS_PER_THREAD;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= quarter) return;
+  const int k = blockIdx.y, c = blockIdx.z, nchunks = cd.num_pp + 1, deg = cd.qdf;
   const u64 beta = betas.v[c], gamma = gammas.v[c];
-  const u64 x = root_pow_d(rt, log_M, (u64)i << (log_M - cd.log_n));
-  const u64 bx = gl_mul(beta, x);
-  u64 nums[MAX_CHUNKS], dens[MAX_CHUNKS];
-  for (int k = 0; k < nchunks; k++) {
+  u64 nums[ZPP_ROWS_PER_THREAD], dens[ZPP_ROWS_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < ZPP_ROWS_PER_THREAD; r++) {
+    const size_t i = t + (size_t)r * quarter;
+    const u64 x = root_pow_d(rt, log_M, (u64)i << (log_M - cd.log_n));
+    const u64 bx = gl_mul(beta, x);
     u64 nu = 1, de = 1;
     for (int j = k * deg; j < (k + 1) * deg && j < cd.num_routed; j++) {
       u64 w = wires[(size_t)j * n + i], sg = sigmas[(size_t)j * n + i];
       nu = gl_mul(nu, gl_add(gl_add(w, gl_mul(bx, cd.k_is[j])), gamma));
       de = gl_mul(de, gl_add(gl_add(w, gl_mul(beta, sg)), gamma));
     }
-    nums[k] = nu; dens[k] = de;
+    nums[r] = nu; dens[r] = de;
   }
-  // batch inversion of the chunk denominators
-  u64 pref[MAX_CHUNKS]; u64 acc = 1;
-  for (int k = 0; k < nchunks; k++) { pref[k] = acc; acc = gl_mul(acc, dens[k]); }
-  u64 inv = gl_inv(acc), tot = 1;
-  u64* qrow = q + ((size_t)c * n + i) * nchunks;
-  for (int k = nchunks - 1; k >= 0; k--) {
-    u64 dinv = gl_mul(inv, pref[k]); inv = gl_mul(inv, dens[k]);
-    nums[k] = gl_mul(nums[k], dinv);
+  u64 pref[ZPP_ROWS_PER_THREAD]; u64 acc = 1;
+#pragma unroll
+  for (int r = 0; r < ZPP_ROWS_PER_THREAD; r++) { pref[r] = acc; acc = gl_mul(acc, dens[r]); }
+  u64 inv = gl_inv(acc);
+#pragma unroll
+  for (int r = ZPP_ROWS_PER_THREAD - 1; r >= 0; r--) {
+    u64 dinv = gl_mul(inv, pref[r]); inv = gl_mul(inv, dens[r]);
+    const size_t i = t + (size_t)r * quarter;
+    q[((size_t)c * n + i) * nchunks + k] = gl_mul(nums[r], dinv);
   }
-  for (int k = 0; k < nchunks; k++) { qrow[k] = nums[k]; tot = gl_mul(tot, nums[k]); }
-  totals[(size_t)c * n + i] = tot;
 }
 
-// Exclusive prefix product of totals (one block per challenge); result overwrites totals: totals[i] = Z(x_i).
-__global__ void __launch_bounds__(1024) k_zpp_scan(u64* totals, int log_n) {
-  __shared__ u64 sm[1024];
-  const size_t n = size_t(1) << log_n;
-  u64* t = totals + (size_t)blockIdx.x * n;
-  const size_t seg = (n + 1023) / 1024, lo = threadIdx.x * seg, hi = lo + seg < n ? lo + seg : n;
-  u64 acc = 1;
-  for (size_t i = lo; i < hi; i++) acc = gl_mul(acc, t[i]);
+// small-n fallback of step 1 (n < 4): one thread per (row, chunk)
+__global__ void k_zpp_chunks_small(CircuitDev cd, const u64* wires, const u64* sigmas, Chal2 betas, Chal2 gammas, u64* q, const u64* rt, int log_M) {
+  const size_t n = size_t(1) << cd.log_n;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y, c = blockIdx.z, nchunks = cd.num_pp + 1, deg = cd.qdf;
+  const u64 beta = betas.v[c], gamma = gammas.v[c];
+  const u64 bx = gl_mul(beta, root_pow_d(rt, log_M, (u64)i << (log_M - cd.log_n)));
+  u64 nu = 1, de = 1;
+  for (int j = k * deg; j < (k + 1) * deg && j < cd.num_routed; j++) {
+    u64 w = wires[(size_t)j * n + i], sg = sigmas[(size_t)j * n + i];
+    nu = gl_mul(nu, gl_add(gl_add(w, gl_mul(bx, cd.k_is[j])), gamma));
+    de = gl_mul(de, gl_add(gl_add(w, gl_mul(beta, sg)), gamma));
+  }
+  q[((size_t)c * n + i) * nchunks + k] = gl_mul(nu, gl_inv(de));
+}
+
+// block-local exclusive prefix products of the row totals; loc[c][i], btot[c][block]
+__global__ void __launch_bounds__(256) k_zpp_scan_local(CircuitDev cd, const u64* __restrict__ q, u64* __restrict__ loc, u64* __restrict__ btot) {
+  __shared__ u64 sm[256];
+  const size_t n = size_t(1) << cd.log_n;
+  const int c = blockIdx.y, nchunks = cd.num_pp + 1;
+  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 8;
+  u64 tot[8]; u64 acc = 1;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const size_t i = base + r; u64 tr = 1;
+    if (i < n) { const u64* qr = q + ((size_t)c * n + i) * nchunks; for (int k = 0; k < nchunks; k++) tr = gl_mul(tr, qr[k]); }
+    tot[r] = tr; acc = gl_mul(acc, tr);
+  }
   sm[threadIdx.x] = acc;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {     // Hillis-Steele inclusive scan (multiplicative)
+  for (int off = 1; off < 256; off <<= 1) {
     u64 v = threadIdx.x >= off ? sm[threadIdx.x - off] : 1;
     __syncthreads();
     sm[threadIdx.x] = gl_mul(sm[threadIdx.x], v);
     __syncthreads();
   }
   u64 run = threadIdx.x ? sm[threadIdx.x - 1] : 1;
-  for (size_t i = lo; i < hi; i++) { u64 v = t[i]; t[i] = run; run = gl_mul(run, v); }
+#pragma unroll
+  for (int r = 0; r < 8; r++) { const size_t i = base + r; if (i < n) loc[(size_t)c * n + i] = run; run = gl_mul(run, tot[r]); }
+  if (threadIdx.x == 255) btot[(size_t)c * gridDim.x + blockIdx.x] = sm[255];
 }
 
-__global__ void __launch_bounds__(256) k_zpp_apply(CircuitDev cd, const u64* q, const u64* totals, u64* zpp) {
+__global__ void __launch_bounds__(256) k_zpp_finish(CircuitDev cd, const u64* __restrict__ q, const u64* __restrict__ loc, const u64* __restrict__ btot,
+                                                    u64* __restrict__ zpp) {
+  __shared__ u64 sm[256];
   const size_t n = size_t(1) << cd.log_n;
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = blockIdx.y, nchunks = cd.num_pp + 1;
-  u64 acc = totals[(size_t)c * n + i];
-  zpp[(size_t)c * n + i] = acc;
-  const u64* qrow = q + ((size_t)c * n + i) * nchunks;
-  for (int k = 0; k < cd.num_pp; k++) { acc = gl_mul(acc, qrow[k]); zpp[(size_t)(cd.num_challenges + c * cd.num_pp + k) * n + i] = acc; }
+  const int c = blockIdx.y, nchunks = cd.num_pp + 1, nblk = gridDim.x;
+  // product of the totals of all blocks before this one
+  u64 acc = 1;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) acc = gl_mul(acc, btot[(size_t)c * nblk + b]);
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] = gl_mul(sm[threadIdx.x], sm[threadIdx.x + off]); __syncthreads(); }
+  const u64 offset = sm[0];
+  for (int r = 0; r < 8; r++) {
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)r * 256 + threadIdx.x;      // coalesced over the block's rows
+    if (i >= n) continue;
+    u64 a = gl_mul(offset, loc[(size_t)c * n + i]);
+    zpp[(size_t)c * n + i] = a;
+    const u64* qr = q + ((size_t)c * n + i) * nchunks;
+    for (int k = 0; k < cd.num_pp; k++) { a = gl_mul(a, qr[k]); zpp[(size_t)(cd.num_challenges + c * cd.num_pp + k) * n + i] = a; }
+  }
 }
 
 void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_vals, Chal2 betas, Chal2 gammas, u64* scratch,
                  u64* zpp_vals, const NttPlan& pl, hipStream_t s) {
   const size_t n = size_t(1) << cd.log_n; const int nch = cd.num_challenges, nchunks = cd.num_pp + 1;
-  u64* q = scratch; u64* totals = scratch + (size_t)nch * n * nchunks;
-  dim3 grid((unsigned)((n + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_zpp_rows, grid, dim3(256), 0, s, cd, wires_vals, sigma_vals, betas, gammas, q, totals, pl.rt, pl.log_M);
-  hipLaunchKernelGGL(k_zpp_scan, dim3(nch), dim3(1024), 0, s, totals, cd.log_n);
-  hipLaunchKernelGGL(k_zpp_apply, grid, dim3(256), 0, s, cd, q, totals, zpp_vals);
+  u64* q = scratch; u64* loc = scratch + (size_t)nch * n * nchunks; u64* btot = loc + (size_t)nch * n;
+  if (n >= 4 * 64) {
+    const size_t quarter = n / ZPP_ROWS_PER_THREAD;
+    hipLaunchKernelGGL(k_zpp_chunks, dim3((unsigned)((quarter + 255) / 256), (unsigned)nchunks, (unsigned)nch), dim3(256), 0, s, cd, wires_vals, sigma_vals,
+                       betas, gammas, q, pl.rt, pl.log_M);
+  } else {
+    hipLaunchKernelGGL(k_zpp_chunks_small, dim3((unsigned)((n + 63) / 64), (unsigned)nchunks, (unsigned)nch), dim3(64), 0, s, cd, wires_vals, sigma_vals,
+                       betas, gammas, q, pl.rt, pl.log_M);
+  }
+  const unsigned nblk = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_zpp_scan_local, dim3(nblk, (unsigned)nch), dim3(256), 0, s, cd, q, loc, btot);
+  hipLaunchKernelGGL(k_zpp_finish, dim3(nblk, (unsigned)nch), dim3(256), 0, s, cd, q, loc, btot, zpp_vals);
 }
 
 // ------------------------------------------------------------------ quotient

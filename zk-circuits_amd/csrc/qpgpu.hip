@@ -124,7 +124,7 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   w->openings = a.take(2 * c->lay.n_openings);
   w->open_partial = a.take(2 * (size_t)(c->S + c->W) * open_chunks(c->log_n));
   w->compose_partial = a.take((size_t)FRI_COMPOSE_GROUPS * 2 * n);
-  w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n); w->pow_result = a.take(4); w->pub_counter = a.take(4);
+  w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n + 4 * (n / 2048 + 2)); w->pow_result = a.take(4); w->pub_counter = a.take(4);
   for (int l = 0; l <= c->nlayers; l++) w->fri_coeffs[l] = a.take((size_t)2 << c->fri_log_n[l]);
   for (int l = 0; l < c->nlayers; l++) {
     size_t Nl = (size_t)1 << (c->fri_log_n[l] + c->rate);
