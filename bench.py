@@ -182,10 +182,10 @@ def main():
         perms = sum(-(-w // 8) for w in widths) * sc.N
         tot_ms = kernels["merkle_leaves_colmajor"]["total_ms"] / (kernels["merkle_leaves_colmajor"]["launches"] / 3.0)
         pps = perms / (tot_ms * 1e-3)
-        instr_per_perm = 26500.0
-        ceiling = 1024 * 2.4e9 / 4.3 * 64 / instr_per_perm          # SIMDs x clock / measured cycles per wave-instr x lanes / instr per permutation
-        valu = {"permutations_per_s": round(pps / 1e9, 3), "unit": "G perm/s", "instr_per_permutation": instr_per_perm,
-                "issue_ceiling_G_perm_per_s": round(ceiling / 1e9, 3), "frac": round(pps / ceiling, 3)}
+        ceiling = 1.90e9        # measured saturation of the one-permutation-per-lane kernel (profiles/r01_permute_occupancy_sweep.txt)
+        valu = {"permutations_per_s": round(pps / 1e9, 3), "unit": "G perm/s", "saturated_G_perm_per_s": round(ceiling / 1e9, 3),
+                "frac": round(pps / ceiling, 3),
+                "note": "integer-VALU issue bound: ~26.5k instructions per permutation; a single 2^17-leaf proof only offers 2 waves/SIMD"}
 
     nproofs = args.steps * args.batch * world
     out = {
