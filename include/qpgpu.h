@@ -76,6 +76,16 @@ int qpgpu_device_count(void);
 int qpgpu_ctx_create(int device, qpgpu_ctx** out);
 void qpgpu_ctx_destroy(qpgpu_ctx* ctx);
 
+/* Parses qp-plonky2's CommonCircuitData::to_bytes() (the `common.bin` the reference writes at
+ * wormhole/circuit-builder/src/lib.rs:36-63 and loads at wormhole/prover/src/lib.rs:105-187; layout: SURVEY.md App. B.1) into
+ * a circuit descriptor. The gate list / selector arrays / k_is are written into caller-provided arrays (capacities given);
+ * constants_sigmas and circuit_digest are NOT in common.bin (they live in prover.bin / verifier.bin) and stay untouched.
+ * Returns 0, or QPGPU_ERR_ARG for malformed / unsupported input (lookups, gates outside the leaf set). */
+int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* desc, qpgpu_gate* gates, size_t gates_cap,
+                       uint32_t* selector_indices, uint32_t* selector_group_ranges, size_t groups_cap, uint64_t* k_is, size_t k_is_cap);
+/* VerifierOnlyCircuitData::to_bytes() (first 8 + 2^cap_height*32 + 32 bytes of `verifier.bin`): cap and circuit digest. */
+int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_out, size_t cap_words, uint64_t digest_out[4]);
+
 /* Uploads the preprocessed columns, computes the constants/sigmas LDE + Merkle tree once and keeps it resident
  * (the work `builder.build_prover()` does at wormhole/circuit/src/circuit.rs:102-104). The handle is immutable and
  * may be shared by threads. */

@@ -91,3 +91,32 @@ def test_prover_commit_is_single_use_without_gpu():
         p.commit(pkg.CircuitInputs.test_inputs())
     with pytest.raises(RuntimeError, match="Failed to prove"):
         p.prove()
+
+
+def test_parse_reference_common_and_verifier_bins():
+    """the reference's serialized circuit artefacts (wormhole/bench-data/common.bin, verifier.bin) load into
+    the C-ABI descriptor; the parsed shape equals the synthetic preset B (which is what pins that preset's shape)."""
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cb = open(os.path.join(G, "common.bin"), "rb").read()
+    vb = open(os.path.join(G, "verifier.bin"), "rb").read()
+    L = qpgpu()
+    d = CircuitDesc(); gates = (Gate * 16)(); sel = (ctypes.c_uint32 * 16)(); grp = (ctypes.c_uint32 * 16)(); kis = (ctypes.c_uint64 * 128)()
+    L.qpgpu_parse_common.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(CircuitDesc), ctypes.POINTER(Gate), ctypes.c_size_t,
+                                     u32p, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t]
+    assert L.qpgpu_parse_common(cb, len(cb), ctypes.byref(d), gates, 16, sel, grp, 8, kis, 128) == 0, L.qpgpu_last_error()
+    sc = SynthCircuit("B"); ref = sc.desc          # keep the owner alive: desc points into it
+    for f in ("degree_bits", "num_wires", "num_routed", "num_constants", "num_challenges", "quotient_degree_factor", "num_partial_products",
+              "num_public_inputs", "num_gate_constraints", "zero_knowledge", "fri_rate_bits", "fri_cap_height", "fri_num_queries",
+              "fri_pow_bits", "fri_num_layers", "num_gates", "num_selector_groups"):
+        assert getattr(d, f) == getattr(ref, f), f
+    assert list(d.fri_arity_bits)[:3] == [4, 4, 4]
+    assert [(gates[i].tag, gates[i].param) for i in range(6)] == [(9, 0), (3, 2), (12, 0), (2, 63), (0, 20), (11, 0)]
+    assert list(sel)[:6] == [0, 0, 0, 0, 0, 1] and list(grp)[:4] == [0, 5, 5, 6]
+    assert [kis[i] for i in range(80)] == [ref.k_is[i] for i in range(80)]
+    # truncated / trailing input is an error, not a crash
+    assert L.qpgpu_parse_common(cb[:-3], len(cb) - 3, ctypes.byref(d), gates, 16, sel, grp, 8, kis, 128) == -1
+    assert L.qpgpu_parse_common(cb + b"x", len(cb) + 1, ctypes.byref(d), gates, 16, sel, grp, 8, kis, 128) == -1
+    cap = (ctypes.c_uint64 * 64)(); dig = (ctypes.c_uint64 * 4)()
+    L.qpgpu_parse_verifier_only.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+    assert L.qpgpu_parse_verifier_only(vb, 552, cap, 64, dig) == 4
+    assert [hex(x) for x in dig] == ["0x8713e1b2b4082ea4", "0x188a85b2cad283d6", "0xd750e61c805b7185", "0xdd6c289a955012e3"]   # SURVEY App. A.6 digest pin

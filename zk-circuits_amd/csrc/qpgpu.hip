@@ -352,6 +352,77 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   *out = c; return 0;
 }
 
+// ---- CommonCircuitData / VerifierOnlyCircuitData parsers (byte layouts: SURVEY.md App. B.1-B.2)
+namespace {
+struct ByteReader {
+  const uint8_t* b; size_t len, pos = 0; bool ok = true;
+  uint64_t u64_() { if (pos + 8 > len) { ok = false; return 0; } uint64_t v; memcpy(&v, b + pos, 8); pos += 8; return v; }
+  uint32_t u32_() { if (pos + 4 > len) { ok = false; return 0; } uint32_t v; memcpy(&v, b + pos, 4); pos += 4; return v; }
+  uint8_t u8_() { if (pos + 1 > len) { ok = false; return 0; } return b[pos++]; }
+};
+bool read_fri_config(ByteReader& r, uint32_t out[4]) {
+  out[0] = (uint32_t)r.u64_(); out[1] = (uint32_t)r.u64_(); out[2] = (uint32_t)r.u64_(); out[3] = r.u32_();
+  uint8_t tag = r.u8_();
+  if (tag == 0) { uint64_t k = r.u64_(); for (uint64_t i = 0; i < k && r.ok; i++) r.u64_(); }
+  else if (tag == 1) { r.u64_(); r.u64_(); }
+  else if (tag == 2) { r.u64_(); }
+  else return false;
+  return r.ok;
+}
+}
+int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* d, qpgpu_gate* gates, size_t gates_cap,
+                       uint32_t* selector_indices, uint32_t* selector_group_ranges, size_t groups_cap, uint64_t* k_is, size_t k_is_cap) {
+  if (!bytes || !d || !gates || !selector_indices || !selector_group_ranges || !k_is) return set_err(QPGPU_ERR_ARG, "null argument");
+  ByteReader r{bytes, len};
+  memset(d, 0, sizeof *d);
+  d->num_wires = (uint32_t)r.u64_(); d->num_routed = (uint32_t)r.u64_(); r.u64_() /*config.num_constants*/; r.u64_() /*security_bits*/;
+  d->num_challenges = (uint32_t)r.u64_(); r.u64_() /*max_quotient_degree_factor*/;
+  r.u8_() /*use_base_arithmetic_gate*/; d->zero_knowledge = r.u8_();
+  uint32_t fc[4];
+  if (!read_fri_config(r, fc) || !read_fri_config(r, fc)) return set_err(QPGPU_ERR_ARG, "malformed FRI config");
+  d->fri_rate_bits = fc[0]; d->fri_cap_height = fc[1]; d->fri_num_queries = fc[2]; d->fri_pow_bits = fc[3];
+  uint64_t na = r.u64_(); if (na > 8) return set_err(QPGPU_ERR_ARG, "too many FRI reduction layers");
+  d->fri_num_layers = (uint32_t)na; for (uint64_t i = 0; i < na; i++) d->fri_arity_bits[i] = (uint32_t)r.u64_();
+  d->degree_bits = (uint32_t)r.u64_(); uint8_t hiding = r.u8_();
+  if ((hiding != 0) != (d->zero_knowledge != 0)) return set_err(QPGPU_ERR_ARG, "fri_params.hiding disagrees with config.zero_knowledge");
+  uint64_t ns = r.u64_(); if (ns > gates_cap) return set_err(QPGPU_ERR_ARG, "selector_indices exceed capacity");
+  for (uint64_t i = 0; i < ns; i++) selector_indices[i] = (uint32_t)r.u64_();
+  uint64_t ng = r.u64_(); if (ng > groups_cap) return set_err(QPGPU_ERR_ARG, "selector groups exceed capacity");
+  for (uint64_t i = 0; i < ng; i++) { selector_group_ranges[2 * i] = (uint32_t)r.u64_(); selector_group_ranges[2 * i + 1] = (uint32_t)r.u64_(); }
+  d->num_selector_groups = (uint32_t)ng;
+  d->quotient_degree_factor = (uint32_t)r.u64_(); d->num_gate_constraints = (uint32_t)r.u64_(); d->num_constants = (uint32_t)r.u64_();
+  d->num_public_inputs = (uint32_t)r.u64_();
+  uint64_t nk = r.u64_(); if (nk > k_is_cap || nk != d->num_routed) return set_err(QPGPU_ERR_ARG, "k_is count mismatch");
+  for (uint64_t i = 0; i < nk; i++) { k_is[i] = r.u64_(); if (k_is[i] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical k_i"); }
+  d->num_partial_products = (uint32_t)r.u64_();
+  uint64_t nlp = r.u64_(), nls = r.u64_(), nluts = r.u64_();
+  if (nlp || nls || nluts) return set_err(QPGPU_ERR_ARG, "lookup arguments are not supported by this backend");
+  uint64_t ngates = r.u64_(); if (ngates > gates_cap || ngates != ns) return set_err(QPGPU_ERR_ARG, "gate count mismatch");
+  for (uint64_t i = 0; i < ngates && r.ok; i++) {
+    gates[i].tag = r.u32_(); gates[i].pad = 0; gates[i].param = 0;
+    switch (gates[i].tag) {
+      case QPGPU_GATE_NOOP: case QPGPU_GATE_PUBLIC_INPUT: case QPGPU_GATE_POSEIDON: break;
+      case QPGPU_GATE_CONSTANT: case QPGPU_GATE_BASESUM2: case QPGPU_GATE_ARITHMETIC: gates[i].param = r.u64_(); break;
+      default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(gates[i].tag) + " is outside the leaf-circuit gate set");
+    }
+  }
+  d->num_gates = (uint32_t)ngates;
+  if (!r.ok) return set_err(QPGPU_ERR_ARG, "common data truncated");
+  if (r.pos != len) return set_err(QPGPU_ERR_ARG, "trailing bytes after common data");
+  d->gates = gates; d->selector_indices = selector_indices; d->selector_group_ranges = selector_group_ranges; d->k_is = k_is;
+  return 0;
+}
+int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_out, size_t cap_words, uint64_t digest_out[4]) {
+  if (!bytes || !cap_out || !digest_out) return set_err(QPGPU_ERR_ARG, "null argument");
+  ByteReader r{bytes, len};
+  uint64_t ch = r.u64_(); if (!r.ok || ch > 20) return set_err(QPGPU_ERR_ARG, "bad cap height");
+  size_t words = (size_t(4)) << ch; if (words > cap_words) return set_err(QPGPU_ERR_BUFFER, "cap buffer too small");
+  for (size_t i = 0; i < words; i++) { cap_out[i] = r.u64_(); if (cap_out[i] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical cap element"); }
+  for (int i = 0; i < 4; i++) digest_out[i] = r.u64_();
+  if (!r.ok) return set_err(QPGPU_ERR_ARG, "verifier data truncated");
+  return (int)ch;
+}
+
 int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit* c, uint64_t* out_cap) {
   if (!c || !out_cap) return set_err(QPGPU_ERR_ARG, "null argument");
   memcpy(out_cap, c->cs_cap.data(), c->cs_cap.size() * 8); return 0;
