@@ -89,3 +89,56 @@ def test_bad_arguments(circuits):
     bad = pis.copy(); bad[0] = P
     with pytest.raises(RuntimeError, match="non-canonical"):
         gc.prove(wires, bad)
+
+
+def test_concurrent_proves_are_reentrant(circuits):
+    """qpgpu_prove from several host threads on one shared circuit handle (the aggregator's rayon workers do this in the
+    reference, wormhole/aggregator/src/circuits/tree.rs:100): each call gets its own stream + workspace."""
+    import threading
+    sc, oc, gc = circuits("T")
+    wits = [sc.witness(500 + i) for i in range(8)]
+    want = [oc.prove(w, p) for w, p in wits]
+    got = [None] * 8
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = gc.prove(wits[i][0], wits[i][1])
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs
+    assert got == want
+
+
+def test_circuit_create_destroy_cycles_and_bad_descriptors():
+    sc = SynthCircuit("T")
+    for _ in range(3):
+        gc = GpuCircuit(sc.desc)
+        w, p = sc.witness(1)
+        assert len(gc.prove(w, p)) == gc.proof_size
+        gc.close()
+    L = qpgpu()
+    ctx = ctypes.c_void_p(); assert L.qpgpu_ctx_create(0, ctypes.byref(ctx)) == 0
+    assert L.qpgpu_ctx_create(99, ctypes.byref(ctypes.c_void_p())) == -1
+    import copy
+    bad = CircuitDesc.from_buffer_copy(sc.desc)
+    bad.gates = (Gate * 6)(*[Gate(13 if i == 3 else sc.desc.gates[i].tag, 0, sc.desc.gates[i].param) for i in range(6)])   # RandomAccess: not in the leaf set
+    h = ctypes.c_void_p()
+    assert L.qpgpu_circuit_create(ctx, ctypes.byref(bad), ctypes.byref(h)) == -1 and b"not supported" in L.qpgpu_last_error()
+    bad2 = CircuitDesc.from_buffer_copy(sc.desc); bad2.fri_arity_bits[0] = 7
+    assert L.qpgpu_circuit_create(ctx, ctypes.byref(bad2), ctypes.byref(h)) == -1
+    L.qpgpu_ctx_destroy(ctx)
+
+
+def test_device_resident_witness_and_caller_stream(circuits):
+    import torch
+    sc, oc, gc = circuits("TZ")
+    w, p = sc.witness(9)
+    wd = torch.from_numpy(w.view(np.int64)).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = gc.prove(None, p, salt_seed=4, wires_dev_ptr=wd.data_ptr(), stream=st.cuda_stream)
+    assert got == oc.prove(w, p, sc.salts(4))

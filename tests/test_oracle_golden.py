@@ -193,5 +193,6 @@ def GpuLayoutSize(d):
 
 
 def test_proof_size_formula_matches_goldens():
-    assert GpuLayoutSize(SynthCircuit("B").desc) == 148932
-    assert GpuLayoutSize(SynthCircuit("A").desc) == 132712
+    b, a = SynthCircuit("B"), SynthCircuit("A")          # keep the owners alive: desc points into them
+    assert GpuLayoutSize(b.desc) == 148932
+    assert GpuLayoutSize(a.desc) == 132712
