@@ -20,6 +20,8 @@ typedef struct qpsynth_params {
   uint32_t n_copies;                       /* number of copy constraints (non-identity sigma entries) */
   uint32_t fri_num_layers; uint32_t fri_arity_bits[8];
   uint64_t circuit_seed;
+  uint32_t fri_cap_height, fri_num_queries, fri_pow_bits;   /* 0 = preset default (4, 28, 16); pow_bits uses 0xFFFFFFFF for "0 bits" */
+  uint32_t reserved;
 } qpsynth_params;
 
 typedef struct qpsynth_circuit qpsynth_circuit;

@@ -142,3 +142,21 @@ def test_device_resident_witness_and_caller_stream(circuits):
     torch.cuda.synchronize()
     got = gc.prove(None, p, salt_seed=4, wires_dev_ptr=wd.data_ptr(), stream=st.cuda_stream)
     assert got == oc.prove(w, p, sc.salts(4))
+
+
+from test_oracle_prover import SHAPES
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+def test_varied_circuit_shapes_match_oracle(shape):
+    """FRI arities 1..4 in mixed schedules, cap heights 0..4, no-reduction FRI, zk, tiny and odd sizes."""
+    sc = SynthCircuit("T", **shape); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+    try:
+        assert np.array_equal(gc.cap(), oc.cap())
+        for seed in (1, 2):
+            w, p = sc.witness(seed)
+            want = oc.prove(w, p, sc.salts(seed) if sc.desc.zero_knowledge else None)
+            got = gc.prove(w, p, salt_seed=seed)
+            assert first_diff(got, want) is None
+    finally:
+        gc.close()

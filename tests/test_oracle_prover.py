@@ -76,3 +76,24 @@ def test_leaf_shape_proof_size_and_verify(preset):
     w, p = sc.witness(0x51570000)
     pf = oc.prove(w, p)
     assert len(pf) == 132712 and oc.verify(pf) is None
+
+
+SHAPES = [
+    dict(degree_bits=5, fri_arity_bits=[1], n_poseidon=2, n_basesum=4, n_arith=4, n_constant=1, n_copies=30),
+    dict(degree_bits=7, fri_arity_bits=[3, 3]),                                                       # last layer tree == its cap (empty paths)
+    dict(degree_bits=7, fri_arity_bits=[1, 2, 4], fri_cap_height=2),
+    dict(degree_bits=7, fri_arity_bits=[2, 2, 2], fri_cap_height=0xFFFFFFFF, fri_num_queries=5),     # cap height 0: a single root
+    dict(degree_bits=9, fri_arity_bits=[4, 4], fri_num_queries=40, fri_pow_bits=10),
+    dict(degree_bits=6, fri_arity_bits=[], fri_pow_bits=0xFFFFFFFF),                                  # no FRI reduction, no grinding
+    dict(degree_bits=9, fri_arity_bits=[4], zero_knowledge=1, fri_cap_height=3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+def test_oracle_prove_verify_on_varied_shapes(shape):
+    sc = SynthCircuit("T", **shape); oc = OracleCircuit(sc.desc)
+    w, p = sc.witness(77)
+    pf = oc.prove(w, p, sc.salts(77) if sc.desc.zero_knowledge else None)
+    assert oc.verify(pf) is None
+    bad = bytearray(pf); bad[len(bad) // 2] ^= 0x10
+    assert oc.verify(bytes(bad)) is not None

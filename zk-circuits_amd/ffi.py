@@ -31,7 +31,8 @@ class CircuitDesc(ctypes.Structure):
 class SynthParams(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint32) for k in ("degree_bits", "zero_knowledge", "n_poseidon", "n_basesum", "n_arith",
                                                "n_constant", "n_copies", "fri_num_layers")] + [
-        ("fri_arity_bits", ctypes.c_uint32 * 8), ("circuit_seed", ctypes.c_uint64)]
+        ("fri_arity_bits", ctypes.c_uint32 * 8), ("circuit_seed", ctypes.c_uint64), ("fri_cap_height", ctypes.c_uint32),
+        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class ProveOpts(ctypes.Structure):

@@ -155,7 +155,10 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   qpgpu_circuit_desc& d = c->desc; memset(&d, 0, sizeof d);
   d.degree_bits = p.degree_bits; d.num_wires = W; d.num_routed = R; d.num_constants = NC; d.num_challenges = 2;
   d.quotient_degree_factor = 8; d.num_partial_products = 9; d.num_public_inputs = NPI; d.num_gate_constraints = 123;
-  d.zero_knowledge = p.zero_knowledge; d.fri_rate_bits = 3; d.fri_cap_height = 4; d.fri_num_queries = 28; d.fri_pow_bits = 16;
+  d.zero_knowledge = p.zero_knowledge; d.fri_rate_bits = 3;
+  d.fri_cap_height = p.fri_cap_height == 0xFFFFFFFFu ? 0 : (p.fri_cap_height ? p.fri_cap_height : 4);
+  d.fri_num_queries = p.fri_num_queries ? p.fri_num_queries : 28;
+  d.fri_pow_bits = p.fri_pow_bits == 0xFFFFFFFFu ? 0 : (p.fri_pow_bits ? p.fri_pow_bits : 16);
   d.fri_num_layers = p.fri_num_layers; for (int i = 0; i < 8; i++) d.fri_arity_bits[i] = p.fri_arity_bits[i];
   d.num_gates = 6; d.num_selector_groups = 2; d.gates = c->gates.data(); d.selector_indices = c->sel_idx.data();
   d.selector_group_ranges = c->groups.data(); d.k_is = c->k_is.data(); d.constants_sigmas = cs;
