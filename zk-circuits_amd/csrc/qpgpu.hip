@@ -191,9 +191,9 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
 }
 
 // Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
-// copied to `cap_host` (pinned) asynchronously.
-static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle, const qpgpu_prove_opts* opts,
-                          u64 salt_seed, const u64* salts_host, u64* cap_host, hipStream_t s) {
+// is fetched by the caller (cap_ptr + fetch_to_host).
+static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
+                          u64 salt_seed, const u64* salts_host, hipStream_t s) {
   const size_t N = c->N;
   { ProfScope ps(w, s, PF_LDE, 8.0 * cols * (c->n + N));
     lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s); }
@@ -208,7 +208,6 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
     merkle_levels(dig, N, c->cap_h, s, done); }
-  (void)cap_host;
 }
 static const u64* cap_ptr(qpgpu_circuit* c, const u64* dig, size_t leaves) {
   return dig + (merkle_total_digests(leaves, c->cap_h) - (size_t(1) << c->cap_h)) * 4;
@@ -343,7 +342,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   Workspace* nows = new Workspace();   // no profiling events for the one-off preprocessing
   values_to_coeffs(c, nows, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
   c->cs_cap.resize(capn * 4);
-  commit_coeffs(c, nows, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, nullptr, 0, nullptr, nullptr, s);
+  commit_coeffs(c, nows, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, 0, nullptr, s);
   CC_TRY(hipStreamSynchronize(s));
   nows->pev_used = 0; ws_destroy(nows);
   CC_TRY(hipGetLastError());
@@ -440,8 +439,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const size_t n = c->n, N = c->N; const qpgpu_circuit_desc& d = c->d; const Layout& L = c->lay;
   const int nch = c->nch, npp = d.num_partial_products; const size_t capn = size_t(1) << c->cap_h;
   const bool timing = getenv_int("QPGPU_TIMING", 0) != 0;
-  hipEvent_t ev[16]; int nev = 0;
-  auto mark = [&]() { if (timing && nev < 16) { (void)hipEventCreate(&ev[nev]); (void)hipEventRecord(ev[nev], s); nev++; } };
+  struct StageEvents { hipEvent_t ev[16]; int n = 0; ~StageEvents() { for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]); } } se;
+  hipEvent_t* ev = se.ev; int& nev = se.n;
+  auto mark = [&]() { if (timing && nev < 16) { if (hipEventCreate(&ev[nev]) == hipSuccess) { (void)hipEventRecord(ev[nev], s); nev++; } } };
   for (uint32_t i = 0; i < d.num_public_inputs; i++) if (pis[i] >= GL_P) return set_err(QPGPU_ERR_WITNESS, "non-canonical public input");
   u64* pin = w->pinned;
   mark();
@@ -450,7 +450,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
-  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, opts, salt_seed, salts_host, pin, s);
+  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s);
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out, pin, L.cap_bytes);
@@ -463,7 +463,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { ProfScope ps(w, s, PF_ZPP, 8.0 * n * (2.0 * d.num_routed + c->Zp));
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
   values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
-  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, opts, salt_seed, salts_host, pin, s);
+  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt_seed, salts_host, s);
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->zs_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + L.cap_bytes, pin, L.cap_bytes);
@@ -476,7 +476,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
-  commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, opts, salt_seed, salts_host, pin, s);
+  commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt_seed, salts_host, s);
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
@@ -488,15 +488,13 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const Ext zinv = ex_inv(zeta), gzinv = ex_inv(gzeta);
   u64 *zp0a = w->zp0, *zp0b = w->zp0 + n + 1, *zp1a = w->zp1, *zp1b = w->zp1 + n + 1;
   u64 *zi0a = w->zi0, *zi0b = w->zi0 + n + 1, *zi1a = w->zi1, *zi1b = w->zi1 + n + 1;
-  ProfScope* pso = new ProfScope(w, s, PF_OPENINGS, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 8));
   {
+    ProfScope ps(w, s, PF_OPENINGS, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 8));
     ExtPowArgs pa; pa.count = n + 1; pa.nbits = c->log_n + 1;
     pa.out_a[0] = zp0a; pa.out_b[0] = zp0b; pa.out_a[1] = zp1a; pa.out_b[1] = zp1b; pa.out_a[2] = zi0a; pa.out_b[2] = zi0b; pa.out_a[3] = zi1a; pa.out_b[3] = zi1b;
     const Ext bases[4] = {zeta, gzeta, zinv, gzinv};
     for (int t = 0; t < 4; t++) { Ext x = bases[t]; for (int k = 0; k < pa.nbits; k++) { pa.pw[t][k] = x; x = ex_mul(x, x); } }
     ext_powers4(pa, s);
-  }
-  {
     u64* o = w->openings;   // proof order: constants|sigmas (S), wires (W), zs (nch), zs_next (nch), pp (nch*npp), quotient (Q)
     open_polys(c->d_cs_coeffs, n, c->S, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->S;
     open_polys(w->wires_coeffs, n, c->W, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->W;
@@ -505,7 +503,6 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)nch * npp;
     open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, w->open_partial, o, s);
   }
-  delete pso;
   { int rc_ = fetch_to_host(w, s, w->openings, 2 * L.n_openings); if (rc_) return rc_; }
   mark();
   memcpy(out + L.openings_off, pin, 16 * L.n_openings);
@@ -517,20 +514,22 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   }
   // ---- 9: FRI
   const Ext fa = ch.challenge_ext();
-  ProfScope* psc = new ProfScope(w, s, PF_FRI_COMBINE, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 24));
-  fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
-              PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->compose_partial, w->comp0, w->comp1, s);
-  fri_divide_combine(w->comp0, w->comp1, c->log_n, zp0a, zp0b, zp1a, zp1b, zi0a, zi0b, zi1a, zi1b, ex_pow(fa, nch), w->div_scratch, w->fri_coeffs[0], s);
-  delete psc;
+  {
+    ProfScope ps(w, s, PF_FRI_COMBINE, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 24));
+    fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
+                PolyGroup{w->q_vals, n, c->Q}, nch, c->log_n, fa, w->compose_partial, w->comp0, w->comp1, s);
+    fri_divide_combine(w->comp0, w->comp1, c->log_n, zp0a, zp0b, zp1a, zp1b, zi0a, zi0b, zi1a, zi1b, ex_pow(fa, nch), w->div_scratch, w->fri_coeffs[0], s);
+  }
   Ext fri_betas[MAX_FRI_LAYERS];
   for (int l = 0; l < c->nlayers; l++) {
     const int lg = c->fri_log_n[l]; const size_t nl = size_t(1) << lg, Nl = nl << c->rate;
-    ProfScope* psl = new ProfScope(w, s, PF_FRI_LAYERS, 8.0 * (2 * nl + 2 * Nl * 2 + 12 * (Nl >> c->arity[l])));
-    lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s);
     const size_t leaves = Nl >> c->arity[l];
-    merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
-    merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
-    delete psl;
+    {
+      ProfScope ps(w, s, PF_FRI_LAYERS, 8.0 * (2 * nl + 2 * Nl * 2 + 12 * leaves));
+      lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s);
+      merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
+      merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
+    }
     { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->fri_dig[l], leaves), capn * 4); if (rc_) return rc_; }
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
     ch.observe_n(pin, capn * 4);
@@ -594,7 +593,6 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   if (timing) {
     g_stage_n = nev - 1;
     for (int i = 0; i + 1 < nev; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); g_stage_ms[i] = ms; }
-    for (int i = 0; i < nev; i++) (void)hipEventDestroy(ev[i]);
   }
   return 0;
 }
