@@ -74,6 +74,8 @@ def main():
     L.qpgpu_profile_name.restype = ctypes.c_char_p
     nwit = min(4, max(1, args.batch)) if args.batch > 1 else 4
     nwit = max(nwit, min(args.batch, 8))
+    if args.preset == "V":
+        nwit = 2                         # 1.1 GB per witness
     seeds = [0x51570000 + rank * 64 + i for i in range(nwit)]
     wit_dev, pis_list = [], []
     for sd in seeds:
@@ -203,6 +205,9 @@ def main():
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample
+    if args.preset == "V" and not args.no_cpu_baseline:
+        args.no_cpu_baseline = True      # one CPU proof at 2^20 rows is minutes of work; outside the bounded-sample budget
+        out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oc = H.OracleCircuit(sc.desc)
         cores = min(available_cores(), H.oracle().orc_max_threads())

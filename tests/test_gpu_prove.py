@@ -160,3 +160,17 @@ def test_varied_circuit_shapes_match_oracle(shape):
             assert first_diff(got, want) is None
     finally:
         gc.close()
+
+
+def test_split_quotient_path_matches_oracle(monkeypatch):
+    """The opt-in split quotient (gate terms / permutation terms on a side stream + alpha combine) gives the same bytes."""
+    monkeypatch.setenv("QPGPU_SPLIT_QUOTIENT", "1")
+    for preset in ("T", "TZ"):
+        sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)     # env is read at circuit creation
+        try:
+            w, p = sc.witness(21)
+            want = oc.prove(w, p, sc.salts(21) if sc.desc.zero_knowledge else None)
+            assert first_diff(gc.prove(w, p, salt_seed=21), want) is None
+            assert first_diff(gc.prove_batch([w, w], [p, p], salt_seed=21)[0], want) is None
+        finally:
+            gc.close()

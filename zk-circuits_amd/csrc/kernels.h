@@ -90,6 +90,14 @@ void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
 void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
                    const u64* alpha_pows, int ap_stride, const u64* pi_hash /*host values*/, u64* out, const NttPlan& pl, hipStream_t s);
 
+// Split form (quotient_split.hip): gate terms G [num_gate_constraints][N] need only wires/constants; permutation terms Pm
+// [nch*(2+npp)][N] need beta/gamma + the Z oracle; the combine needs alpha. Lets the first two run off the critical path.
+bool quotient_split_supported(const CircuitDev& cd);
+void quotient_gate_terms(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* pi_hash, u64* G, hipStream_t s);
+void quotient_perm_terms(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas, u64* Pm,
+                         const NttPlan& pl, hipStream_t s);
+void quotient_combine(const CircuitDev& cd, const u64* Pm, const u64* G, const u64* alpha_pows, int ap_stride, u64* out, hipStream_t s);
+
 // out_a[i], out_b[i] = scale * base^i in F_{p^2}, i < count
 void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipStream_t s);
 // Four power tables in one launch: out[t][i] = base_t^i (i < count), given pw[t][k] = base_t^(2^k).

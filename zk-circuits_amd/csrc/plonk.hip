@@ -20,7 +20,6 @@ __device__ __forceinline__ u64 root_pow_d(const u64* rt, int log_M, u64 e) {
 // 2. k_zpp_scan_local: blocks of 2048 rows: row totals, block-local exclusive prefix products, block totals.
 // 3. k_zpp_finish: every block multiplies in the product of the preceding block totals (<= 512 of them) and writes Z and
 //    the running partial products. No single-block pass: the old one-block scan was 34 us of strided 8-byte loads.
-static constexpr int MAX_CHUNKS = 16;
 static constexpr int ZPP_ROWS_PER_THREAD = 4;
 static constexpr int SCAN_BLOCK = 2048;     // rows per scan block (256 threads x 8)
 

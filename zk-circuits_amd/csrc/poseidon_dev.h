@@ -203,31 +203,36 @@ __device__ __forceinline__ void poseidon_permute_pair(u64 own[6], const PairCtx&
 // (upper Merkle levels, FRI layer leaves). `xch` is this group's 12-u64 exchange slot in LDS; the caller's block is ONE wave
 // (64 threads), so the barriers below are wave-local.
 struct CoopCtx {
-  u64 rc[30];     // this lane's round constants
   u32 m[12];      // this lane's MDS row: m[j] multiplies element j
+  int ii;         // element index of this lane (0 for the idle lanes 12..15)
 };
 __device__ __forceinline__ void coop_init(CoopCtx& cx, int i) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   const int ii = i < 12 ? i : 0;
-#pragma unroll
-  for (int r = 0; r < 30; r++) cx.rc[r] = POSEIDON_RC_DEV[12 * r + ii];
+  cx.ii = ii;
 #pragma unroll
   for (int j = 0; j < 12; j++) cx.m[j] = C[(j - ii + 12) % 12] + ((ii == 0 && j == 0) ? 8u : 0u);
 }
 // x: this lane's element (canonical or lazy in; canonical out). All 64 lanes of the wave must call this.
 // `xch` points at TWO 12-slot exchange buffers (24 u64) used alternately, so one barrier per round suffices (a wave-scope
 // fence with volatile LDS accesses was measured 40 % SLOWER than s_barrier here: it serialises the twelve ds_reads).
+// The round loop stays rolled (30 x ~150 instructions); the next round's constant is a plain global load issued a full
+// round ahead, so its latency hides behind the S-box. (Keeping the 30 per-lane constants in a register array made the
+// compiler spill them to scratch once the loop was not unrolled: 296 B/lane of scratch traffic on the critical path.)
 __device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64* xch) {
-  x = add_lazy_canon(x, cx.rc[0]);
-#pragma unroll
+  const u64* __restrict__ rcl = POSEIDON_RC_DEV + cx.ii;
+  x = add_lazy_canon(x, rcl[0]);
+  u64 c_next = rcl[12];
   for (int r = 0; r < 30; r++) {
     const bool full = r < 4 || r >= 26;
+    const u64 c = c_next;
+    c_next = r + 2 < 30 ? rcl[12 * (r + 2)] : 0;      // prefetch
     if (full || i == 0) x = sbox7_lazy(x);
     u64* buf = xch + (r & 1) * 12;
     if (i < 12) buf[i] = x;
     __syncthreads();
-    u64 c = r + 1 < 30 ? cx.rc[r + 1] : 0;
-    u64 sl = (u32)c, sh = c >> 32;
+    const u64 cc = r + 1 < 30 ? c : 0;
+    u64 sl = (u32)cc, sh = cc >> 32;
 #pragma unroll
     for (int j = 0; j < 12; j++) { u64 v = buf[j]; sl = mad32((u32)v, cx.m[j], sl); sh = mad32((u32)(v >> 32), cx.m[j], sh); }
     u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);

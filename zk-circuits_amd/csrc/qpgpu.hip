@@ -59,6 +59,8 @@ static constexpr int PROF_EVENTS = 128;
 struct Workspace {
   hipEvent_t pev[PROF_EVENTS]; int pev_made = 0, pev_used = 0; int pev_id[PROF_EVENTS / 2]; double pev_bytes[PROF_EVENTS / 2];
   DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_gates = nullptr, ev_perm = nullptr;   // off-critical-path quotient parts
+  u64 *q_gate_terms = nullptr, *q_perm_terms = nullptr;
   u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
   u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
   u64 pub_seq = 0;
@@ -82,6 +84,7 @@ struct qpgpu_circuit {
   u64* d_fri_scale[MAX_FRI_LAYERS + 1] = {nullptr};
   u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_dig = nullptr;
   std::vector<u64> cs_cap;
+  bool split_quotient = false;
   Layout lay; size_t ws_bytes = 0;
   std::mutex mu; std::vector<Workspace*> free_ws;
 };
@@ -120,6 +123,7 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   w->zs_lde = a.take((size_t)(c->Zp + s) * N); w->zs_dig = a.take(merkle_total_digests(N, c->cap_h) * 4);
   w->q_vals = a.take((size_t)c->nch * N); w->q_lde = a.take((size_t)(c->Q + s) * N); w->q_dig = a.take(merkle_total_digests(N, c->cap_h) * 4);
   w->alpha_pows = a.take((size_t)c->nch * 256);
+  if (c->split_quotient) { w->q_gate_terms = a.take((size_t)c->d.num_gate_constraints * N); w->q_perm_terms = a.take((size_t)c->nch * (2 + c->d.num_partial_products) * N); }
   w->zp0 = a.take(2 * (n + 1)); w->zp1 = a.take(2 * (n + 1)); w->zi0 = a.take(2 * (n + 1)); w->zi1 = a.take(2 * (n + 1));
   w->openings = a.take(2 * c->lay.n_openings);
   w->open_partial = a.take(2 * (size_t)(c->S + c->W) * open_chunks(c->log_n));
@@ -135,6 +139,7 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   return a.used;
 }
 
+static void ws_destroy(Workspace* w);
 static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
   {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -146,8 +151,16 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
   if (e != hipSuccess) { delete w; return set_err(QPGPU_ERR_OOM, std::string("workspace hipMalloc: ") + hipGetErrorString(e)); }
   w->arena.size = c->ws_bytes;
   plan_workspace(c, w);
-  e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
+  e = hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, prio_hi);
   if (e != hipSuccess) { (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_HIP, "hipStreamCreate failed"); }
+  if (c->split_quotient) {
+    // the side stream carries throughput work that must not delay the latency-critical tree levels on the main stream
+    if (hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_lo) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w->ev_gates, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_perm, hipEventDisableTiming) != hipSuccess) {
+      ws_destroy(w); return set_err(QPGPU_ERR_HIP, "side stream / event creation failed");
+    }
+  }
   w->pinned_elems = 4096 + 2 * c->lay.n_openings + (c->lay.bytes_per_query * c->d.fri_num_queries) / 8 + 64;
   e = hipHostMalloc((void**)&w->pinned, (w->pinned_elems + 8) * 8, hipHostMallocMapped);
   if (e != hipSuccess) { (void)hipStreamDestroy(w->stream); (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_OOM, "hipHostMalloc failed"); }
@@ -162,6 +175,8 @@ static void ws_destroy(Workspace* w) {
   for (int i = 0; i < w->pev_made; i++) (void)hipEventDestroy(w->pev[i]);
   if (w->pinned) (void)hipHostFree(w->pinned);
   if (w->stream) (void)hipStreamDestroy(w->stream);
+  if (w->side) (void)hipStreamDestroy(w->side);
+  for (hipEvent_t e : {w->ev_fork, w->ev_gates, w->ev_perm}) if (e) (void)hipEventDestroy(e);
   if (w->arena.base) (void)hipFree(w->arena.base);
   delete w;
 }
@@ -192,8 +207,13 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
 
 // Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
 // is fetched by the caller (cap_ptr + fetch_to_host).
+// `fork` (optional) is invoked once the LDE (+ salt) is enqueued, before the leaf hash: work forked there onto the side stream
+// runs beside the leaf-hash kernel, which at N = 2^17 only offers 2 waves/SIMD and leaves ~15 % of the issue slots unused
+// (profiles/r01_permute_occupancy_sweep.txt). Forking AFTER the leaf hash instead — beside the latency-bound upper levels — was
+// measured to slow every level launch by ~1.3x and lose what the overlap gained.
+template <class F>
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
-                          u64 salt_seed, const u64* salts_host, hipStream_t s) {
+                          u64 salt_seed, const u64* salts_host, hipStream_t s, F fork) {
   const size_t N = c->N;
   { ProfScope ps(w, s, PF_LDE, 8.0 * cols * (c->n + N));
     lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s); }
@@ -203,11 +223,16 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     else salt_fill(lde + (size_t)cols * N, N, salt_seed, oracle - 1, s);
     width += 4;
   }
+  fork();
   int done = 0;
   { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
     done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
     merkle_levels(dig, N, c->cap_h, s, done); }
+}
+static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
+                          u64 salt_seed, const u64* salts_host, hipStream_t s) {
+  commit_coeffs(c, w, coeffs, cols, lde, dig, oracle, salt_seed, salts_host, s, [] {});
 }
 static const u64* cap_ptr(qpgpu_circuit* c, const u64* dig, size_t leaves) {
   return dig + (merkle_total_digests(leaves, c->cap_h) - (size_t(1) << c->cap_h)) * 4;
@@ -347,6 +372,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   nows->pev_used = 0; ws_destroy(nows);
   CC_TRY(hipGetLastError());
   { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
+  c->split_quotient = quotient_split_supported(c->cd);
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
   *out = c; return 0;
 }
@@ -450,7 +476,13 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
-  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s);
+  const bool split = c->split_quotient;
+  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s, [&] {
+    if (!split) return;                       // gate-constraint terms: only wires + constants, run beside the wires leaf hash
+    (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
+    quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, w->side);
+    (void)hipEventRecord(w->ev_gates, w->side);
+  });
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out, pin, L.cap_bytes);
@@ -463,7 +495,12 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { ProfScope ps(w, s, PF_ZPP, 8.0 * n * (2.0 * d.num_routed + c->Zp));
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
   values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
-  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt_seed, salts_host, s);
+  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt_seed, salts_host, s, [&] {
+    if (!split) return;                       // permutation terms: beta/gamma + Z oracle, run beside the Z leaf hash
+    (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
+    quotient_perm_terms(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->q_perm_terms, c->pl, w->side);
+    (void)hipEventRecord(w->ev_perm, w->side);
+  });
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->zs_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + L.cap_bytes, pin, L.cap_bytes);
@@ -473,7 +510,10 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
   alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
   { ProfScope ps(w, s, PF_QUOTIENT, 8.0 * N * (c->S + c->W + c->Zp + 2 * nch));
-    quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
+    if (split) {
+      (void)hipStreamWaitEvent(s, w->ev_gates, 0); (void)hipStreamWaitEvent(s, w->ev_perm, 0);
+      quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
+    } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
   commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt_seed, salts_host, s);
