@@ -1,7 +1,7 @@
 """The host-side mirror of the reference wrappers on a real GPU: WormholeProver new/commit/prove (reference:
 wormhole/prover/src/lib.rs:190-237, tests wormhole/tests/src/prover/prover_tests.rs:14-45) and the aggregator's leaf
 batch (wormhole/tests/src/aggregator/aggregator_tests.rs:11-112), plus a large Merkle tree through the fused leaf kernel."""
-import importlib
+import importlib, os
 import numpy as np
 import pytest
 from harness import *
@@ -72,3 +72,14 @@ def test_large_merkle_tree_fused_levels():
     got = np.zeros((tot, 4), dtype=np.uint64)
     gpu_check(qpgpu().qpgpu_test_merkle(ptr(cols), width, leaves, cap, ptr(got)))
     assert np.array_equal(got, exp)
+
+
+def test_cpp_host_mirror_example_runs():
+    """examples/prove_example.cc drives zk-circuits_amd/host/wormhole.hpp end to end (new -> commit -> prove, aggregator buffer)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "prove_example")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for mode, size in (("nozk", 132712), ("zk", 148932)):
+        r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "proof bytes %d" % size in r.stdout and "second commit rejected: prover has already commited to inputs" in r.stdout

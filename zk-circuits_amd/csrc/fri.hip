@@ -12,9 +12,15 @@ namespace qp {
 // each step acc*alpha + f is two 2-term dot products with a single reduction each.
 struct ComposeArgs { PolyGroup g[4]; int total; int per_group; Ext alpha; Ext alpha_run; /* alpha^per_group */ };
 __device__ __forceinline__ u64 compose_coeff(const ComposeArgs& a, int j, size_t i) {
+  // explicit chain (no indexed access into the argument struct: that put the whole struct into scratch)
   int k = j;
-#pragma unroll
-  for (int gi = 0; gi < 4; gi++) { if (k < a.g[gi].count) return a.g[gi].base[(size_t)k * a.g[gi].stride + i]; k -= a.g[gi].count; }
+  if (k < a.g[0].count) return a.g[0].base[(size_t)k * a.g[0].stride + i];
+  k -= a.g[0].count;
+  if (k < a.g[1].count) return a.g[1].base[(size_t)k * a.g[1].stride + i];
+  k -= a.g[1].count;
+  if (k < a.g[2].count) return a.g[2].base[(size_t)k * a.g[2].stride + i];
+  k -= a.g[2].count;
+  if (k < a.g[3].count) return a.g[3].base[(size_t)k * a.g[3].stride + i];
   return 0;
 }
 __global__ void __launch_bounds__(256) k_fri_compose_partial(ComposeArgs a, size_t n, u64* partial) {
