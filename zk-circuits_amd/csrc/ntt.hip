@@ -132,6 +132,11 @@ static void run_passes(const u64* in, size_t in_stride, u64* out, size_t out_str
     int m = a.b_hi - a.b_lo;
     if (a.b_lo == 0) { a.t = 0; a.tile_log = log_n < TL_MAX ? log_n : TL_MAX; if (a.tile_log < m) a.tile_log = m; }
     else { int t = TL_MAX - m; if (t > a.b_lo) t = a.b_lo; if (t > 4) t = 4; a.t = t; a.tile_log = m + t; }
+    // few transforms (quotient iNTT, FRI layers: 2 columns): shrink the tile until the launch has enough workgroups for the chip
+    while (((size_t(1) << log_n) >> a.tile_log) * (size_t)(count * cosets) < 1024) {
+      if (a.b_lo == 0) { if (a.tile_log <= m || a.tile_log <= 8) break; a.tile_log--; }
+      else { if (a.t <= 2) break; a.t--; a.tile_log--; }
+    }
     if (!first && a.pre == nullptr && log_cosets) {
       // later passes of an LDE operate in place on the output blocks: source == destination block
       a.in = out; a.in_stride = out_stride;
