@@ -82,7 +82,7 @@ struct Chal2 { u64 v[2]; };
 // ordered [Z_0..Z_{nch-1}, pp_0(npp), pp_1(npp)...]. scratch: q [nch][n][npp+1] + local prefixes [nch][n] + block totals.
 void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_vals, Chal2 betas, Chal2 gammas, u64* scratch,
                  u64* zpp_vals, const NttPlan& pl, hipStream_t s);
-static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2) + (size_t)nch * (n / 2048 + 2); }
+static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2) + (size_t)nch * (n / 512 + 2); }
 
 // alpha power table: out[c][i] = alpha_c^i, i < count
 void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);

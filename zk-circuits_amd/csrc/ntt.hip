@@ -165,7 +165,8 @@ void lde_batch_generic(const u64* in, size_t in_stride, u64* out, size_t out_str
 void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
                const u64* scale, const NttPlan& pl, hipStream_t s) {
   if (count <= 0) return;
-  if (ntt16_supported(log_n)) { ntt16_run(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, 1, pl, s); return; }
+  // one workgroup per transform in ntt16: with only a handful of transforms (FRI layers) the tiled kernel spreads better
+  if (ntt16_supported(log_n) && (count << log_cosets) >= 64) { ntt16_run(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, 1, pl, s); return; }
   run_passes(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, nullptr, pl, s);
 }
 

@@ -18,10 +18,11 @@ __device__ __forceinline__ u64 root_pow_d(const u64* rt, int log_M, u64 e) {
 // 1. k_zpp_chunks: one thread per (4 rows, chunk of `qdf` routed wires, challenge): numerator / denominator products and one
 //    shared inversion (Montgomery trick over the 4 rows) -> chunk quotients q[c][row][chunk].
 // 2. k_zpp_scan_local: blocks of 2048 rows: row totals, block-local exclusive prefix products, block totals.
-// 3. k_zpp_finish: every block multiplies in the product of the preceding block totals (<= 512 of them) and writes Z and
+// 3. k_zpp_finish: every block multiplies in the product of the preceding block totals (n/512 of them) and writes Z and
 //    the running partial products. No single-block pass: the old one-block scan was 34 us of strided 8-byte loads.
 static constexpr int ZPP_ROWS_PER_THREAD = 4;
-static constexpr int SCAN_BLOCK = 2048;     // rows per scan block (256 threads x 8)
+static constexpr int SCAN_ROWS = 2;          // rows per thread in the scan kernels (small: the scan is latency-bound, not work-bound)
+static constexpr int SCAN_BLOCK = 256 * SCAN_ROWS;   // rows per scan block
 
 __global__ void __launch_bounds__(256) k_zpp_chunks(CircuitDev cd, const u64* __restrict__ wires, const u64* __restrict__ sigmas, Chal2 betas,
                                                     Chal2 gammas, u64* __restrict__ q, const u64* __restrict__ rt, int log_M) {
@@ -78,10 +79,10 @@ __global__ void __launch_bounds__(256) k_zpp_scan_local(CircuitDev cd, const u64
   __shared__ u64 sm[256];
   const size_t n = size_t(1) << cd.log_n;
   const int c = blockIdx.y, nchunks = cd.num_pp + 1;
-  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 8;
-  u64 tot[8]; u64 acc = 1;
+  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ROWS;
+  u64 tot[SCAN_ROWS]; u64 acc = 1;
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < SCAN_ROWS; r++) {
     const size_t i = base + r; u64 tr = 1;
     if (i < n) { const u64* qr = q + ((size_t)c * n + i) * nchunks; for (int k = 0; k < nchunks; k++) tr = gl_mul(tr, qr[k]); }
     tot[r] = tr; acc = gl_mul(acc, tr);
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) k_zpp_scan_local(CircuitDev cd, const u64
   }
   u64 run = threadIdx.x ? sm[threadIdx.x - 1] : 1;
 #pragma unroll
-  for (int r = 0; r < 8; r++) { const size_t i = base + r; if (i < n) loc[(size_t)c * n + i] = run; run = gl_mul(run, tot[r]); }
+  for (int r = 0; r < SCAN_ROWS; r++) { const size_t i = base + r; if (i < n) loc[(size_t)c * n + i] = run; run = gl_mul(run, tot[r]); }
   if (threadIdx.x == 255) btot[(size_t)c * gridDim.x + blockIdx.x] = sm[255];
 }
 
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) k_zpp_finish(CircuitDev cd, const u64* __
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) sm[threadIdx.x] = gl_mul(sm[threadIdx.x], sm[threadIdx.x + off]); __syncthreads(); }
   const u64 offset = sm[0];
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < SCAN_ROWS; r++) {
     const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)r * 256 + threadIdx.x;      // coalesced over the block's rows
     if (i >= n) continue;
     u64 a = gl_mul(offset, loc[(size_t)c * n + i]);
