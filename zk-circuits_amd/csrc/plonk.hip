@@ -20,7 +20,7 @@ __device__ __forceinline__ u64 root_pow_d(const u64* rt, int log_M, u64 e) {
 // 2. k_zpp_scan_local: blocks of 2048 rows: row totals, block-local exclusive prefix products, block totals.
 // 3. k_zpp_finish: every block multiplies in the product of the preceding block totals (n/512 of them) and writes Z and
 //    the running partial products. No single-block pass: the old one-block scan was 34 us of strided 8-byte loads.
-static constexpr int ZPP_ROWS_PER_THREAD = 4;
+static constexpr int ZPP_ROWS_PER_THREAD = 2;
 static constexpr int SCAN_ROWS = 2;          // rows per thread in the scan kernels (small: the scan is latency-bound, not work-bound)
 static constexpr int SCAN_BLOCK = 256 * SCAN_ROWS;   // rows per scan block
 
@@ -127,7 +127,7 @@ void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_v
                  u64* zpp_vals, const NttPlan& pl, hipStream_t s) {
   const size_t n = size_t(1) << cd.log_n; const int nch = cd.num_challenges, nchunks = cd.num_pp + 1;
   u64* q = scratch; u64* loc = scratch + (size_t)nch * n * nchunks; u64* btot = loc + (size_t)nch * n;
-  if (n >= 4 * 64) {
+  if (n >= ZPP_ROWS_PER_THREAD * 64) {
     const size_t quarter = n / ZPP_ROWS_PER_THREAD;
     hipLaunchKernelGGL(k_zpp_chunks, dim3((unsigned)((quarter + 255) / 256), (unsigned)nchunks, (unsigned)nch), dim3(256), 0, s, cd, wires_vals, sigma_vals,
                        betas, gammas, q, pl.rt, pl.log_M);
