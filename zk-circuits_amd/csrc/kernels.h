@@ -26,8 +26,9 @@ void ntt_copy(const u64* in, size_t in_stride, u64* out, size_t out_stride, int 
 // Low-degree extension: for each of `count` coefficient columns (n = 2^log_n coefficients at in + c*in_stride) writes
 // 2^(log_n+log_cosets) values at out + c*out_stride in LEAF order (bit-reversed natural index):
 // block rev(c) holds the size-n DIF transform of coset c. scale = build_lde_scale table.
+// shared_gpu: other proofs' kernels run beside this launch (qpgpu_prove_batch) — selects the kernel that co-runs best.
 void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
-               const u64* scale, const NttPlan& pl, hipStream_t s);
+               const u64* scale, const NttPlan& pl, hipStream_t s, bool shared_gpu = false);
 void lde_batch_generic(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
                        const u64* scale, const NttPlan& pl, hipStream_t s);   // tiled multi-pass kernel only (any size)
 // out[i] = in[rev(i)] * scale  for `count` columns
@@ -42,6 +43,9 @@ void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int
 // host memory, fences at system scope and then stores `seq` into *flag (also pinned); the host spins on the flag.
 // Measured 7.5 us per hand-off versus 15.2 us for hipMemcpyAsync + hipStreamSynchronize (tools/ubench notes in DESIGN.md).
 void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s);
+bool lde_strided_supported(int log_n);
+void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, const u64* pre,
+                     const NttPlan& pl, hipStream_t s);
 // cols[k][L] = salt_value(seed, (oracle*4 + k)*N + L) for k < 4 (salt.h)
 void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
 
@@ -55,7 +59,7 @@ int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t
 void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s);
 // Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to
 // 2^cap_height digests. Returns (host-side) nothing; layout helper below.
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0);
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0, bool shared_gpu = false);
 static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
   size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
 }

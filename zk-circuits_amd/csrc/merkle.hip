@@ -244,13 +244,18 @@ __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size
   if (p < parents && i < 4) out[p * 4 + i] = x;
 }
 static constexpr size_t COOP_MAX_PARENTS = 16384;
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done) {
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done, bool shared_gpu) {
+  // (Tried for batch mode: per-lane kernels down to 2048 parents, because the 16-lane form costs ~3x the instructions per
+  // permutation. Stream-pipelined throughput did not improve — 257-278 vs 285 proofs/s — the longer per-proof critical path
+  // costs more overlap than the saved instructions buy, so both modes use the same thresholds.)
+  (void)shared_gpu;
+  const size_t pair_max = PAIR_MAX_LEAVES, coop_max = COOP_MAX_PARENTS;
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
   for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {
     size_t parents = cnt >> 1; u64* out = cur + cnt * 4;
-    if (parents > PAIR_MAX_LEAVES) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
-    else if (parents > COOP_MAX_PARENTS) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
+    if (parents > (pair_max > coop_max ? pair_max : coop_max)) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
+    else if (parents > coop_max) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
     else hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, cur, out, parents);
     cur = out; cnt = parents;
   }

@@ -163,10 +163,13 @@ void lde_batch_generic(const u64* in, size_t in_stride, u64* out, size_t out_str
   run_passes(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, nullptr, pl, s);
 }
 void lde_batch(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets,
-               const u64* scale, const NttPlan& pl, hipStream_t s) {
+               const u64* scale, const NttPlan& pl, hipStream_t s, bool shared_gpu) {
   if (count <= 0) return;
   // one workgroup per transform in ntt16: with only a handful of transforms (FRI layers) the tiled kernel spreads better
   if (ntt16_supported(log_n) && (count << log_cosets) >= 64) { ntt16_run(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, 1, pl, s); return; }
+  // strided radix-16 passes: 1.4-1.6x faster than the tiled kernel when the launch owns the chip (single proof: 4.54 vs 4.68 ms);
+  // with several proofs in flight its 35 KB-LDS block pass co-runs worse (277 vs 287 proofs/s), so batch mode keeps the tiled kernel.
+  if (!shared_gpu && lde_strided_supported(log_n) && (count << log_cosets) >= 64) { lde_strided_run(in, in_stride, out, out_stride, count, log_n, log_cosets, scale, pl, s); return; }
   run_passes(in, in_stride, out, out_stride, count, log_n, log_cosets, false, false, scale, nullptr, pl, s);
 }
 

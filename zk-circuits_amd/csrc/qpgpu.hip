@@ -64,6 +64,7 @@ struct Workspace {
   u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
   u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
   u64 pub_seq = 0;
+  bool shared_gpu = false;    // set for workers of qpgpu_prove_batch: several proofs share the chip
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
   u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
@@ -216,7 +217,7 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
                           u64 salt_seed, const u64* salts_host, hipStream_t s, F fork) {
   const size_t N = c->N;
   { ProfScope ps(w, s, PF_LDE, 8.0 * cols * (c->n + N));
-    lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s); }
+    lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s, w->shared_gpu); }
   int width = cols;
   if (c->salt && oracle > 0) {
     if (salts_host) (void)hipMemcpyAsync(lde + (size_t)cols * N, salts_host + (size_t)(oracle - 1) * 4 * N, 4 * N * 8, hipMemcpyHostToDevice, s);
@@ -228,7 +229,7 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
   { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
     done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
-    merkle_levels(dig, N, c->cap_h, s, done); }
+    merkle_levels(dig, N, c->cap_h, s, done, w->shared_gpu); }
 }
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
                           u64 salt_seed, const u64* salts_host, hipStream_t s) {
@@ -566,9 +567,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const size_t leaves = Nl >> c->arity[l];
     {
       ProfScope ps(w, s, PF_FRI_LAYERS, 8.0 * (2 * nl + 2 * Nl * 2 + 12 * leaves));
-      lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s);
+      lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s, w->shared_gpu);
       merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
-      merkle_levels(w->fri_dig[l], leaves, c->cap_h, s);
+      merkle_levels(w->fri_dig[l], leaves, c->cap_h, s, 0, w->shared_gpu);
     }
     { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->fri_dig[l], leaves), capn * 4); if (rc_) return rc_; }
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
@@ -677,6 +678,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
+    w->shared_gpu = workers > 1;
     for (;;) {
       size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
       qpgpu_prove_opts o; if (opts) o = *opts; else memset(&o, 0, sizeof o);
@@ -686,6 +688,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
       if (rc) { (void)hipStreamSynchronize(w->stream); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
       if (out_lens) out_lens[i] = c->lay.total;
     }
+    w->shared_gpu = false;
     ws_release(c, w);
   };
   std::vector<std::thread> th;
