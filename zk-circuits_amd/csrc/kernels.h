@@ -44,8 +44,9 @@ void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int
 // Measured 7.5 us per hand-off versus 15.2 us for hipMemcpyAsync + hipStreamSynchronize (tools/ubench notes in DESIGN.md).
 void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s);
 bool lde_strided_supported(int log_n);
+// natural-order in -> bit-reversed out (coset blocks as in lde_batch); inverse = conjugate roots, unscaled
 void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, const u64* pre,
-                     const NttPlan& pl, hipStream_t s);
+                     const NttPlan& pl, hipStream_t s, bool inverse = false);
 // cols[k][L] = salt_value(seed, (oracle*4 + k)*N + L) for k < 4 (salt.h)
 void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s);
 

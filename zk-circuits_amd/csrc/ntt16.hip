@@ -256,11 +256,11 @@ bool lde_strided_supported(int log_n) {
   return !disabled && log_n >= 13 && log_n <= 24;
 }
 void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, const u64* pre,
-                     const NttPlan& pl, hipStream_t s) {
+                     const NttPlan& pl, hipStream_t s, bool inverse) {
   if (count <= 0) return;
   StridedArgs a; a.in = in; a.in_stride = in_stride; a.out = out; a.out_stride = out_stride; a.pre = pre; a.rt = pl.rt; a.log_M = pl.log_M;
-  a.log_n = log_n; a.log_cosets = log_cosets; a.inverse = 0;
-  { u64 w = gl_root(4), x = 1; for (int j = 0; j < 8; j++) { a.w16.w[j] = x; x = gl_mul(x, w); } }
+  a.log_n = log_n; a.log_cosets = log_cosets; a.inverse = inverse ? 1 : 0;
+  { u64 w = gl_root(4); if (inverse) w = gl_inv(w); u64 x = 1; for (int j = 0; j < 8; j++) { a.w16.w[j] = x; x = gl_mul(x, w); } }
   const size_t n = size_t(1) << log_n; const unsigned transforms = (unsigned)(count << log_cosets);
   int rem = log_n; bool first = true;
   while (rem > 12) {
@@ -280,7 +280,7 @@ void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_strid
     rem -= M; first = false;
   }
   // remaining contiguous blocks of 2^rem: pure DIF of that size each, in place
-  Ntt16Args b; b.in = out; b.out = out; b.pre = nullptr; b.rt = pl.rt; b.log_M = pl.log_M; b.scale = 1; b.log_cosets = 0; b.inverse = 0; b.out_natural = 0;
+  Ntt16Args b; b.in = out; b.out = out; b.pre = nullptr; b.rt = pl.rt; b.log_M = pl.log_M; b.scale = 1; b.log_cosets = 0; b.inverse = a.inverse; b.out_natural = 0;
   b.w16 = a.w16;
   // every 2^rem block of every (column, coset) output is one transform; with contiguous columns all blocks are evenly spaced
   const size_t blocks_per_col = (n << log_cosets) >> rem;

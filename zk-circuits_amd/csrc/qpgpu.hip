@@ -242,6 +242,11 @@ static const u64* cap_ptr(qpgpu_circuit* c, const u64* dig, size_t leaves) {
 static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, int cols, u64* tmp, u64* coeffs, hipStream_t s) {
   ProfScope ps(w, s, PF_INTT, 8.0 * cols * c->n * 2);
   if (ntt16_supported(c->log_n)) { ntt16_run(vals, c->n, coeffs, c->n, cols, c->log_n, 0, true, true, nullptr, gl_inv((u64)c->n), c->pl, s); return; }
+  if (!w->shared_gpu && lde_strided_supported(c->log_n) && cols >= 16) {        // same kernel choice rule as lde_batch
+    lde_strided_run(vals, c->n, tmp, c->n, cols, c->log_n, 0, nullptr, c->pl, s, true);
+    bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
+    return;
+  }
   ntt_copy(vals, c->n, tmp, c->n, cols, c->log_n, false, true, c->pl, s);             // inverse DIF: bit-reversed, unscaled
   bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
 }
