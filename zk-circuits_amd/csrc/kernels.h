@@ -108,10 +108,13 @@ void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipSt
 // Four power tables in one launch: out[t][i] = base_t^i (i < count), given pw[t][k] = base_t^(2^k).
 struct ExtPowArgs { u64* out_a[4]; u64* out_b[4]; Ext pw[4][28]; size_t count; int nbits; };
 void ext_powers4(const ExtPowArgs& a, hipStream_t s);
-// Openings (row a9): out[p] = sum_i polys[p][i] * zp[i]  for p < count; out as interleaved (a,b) pairs.
-// partial: scratch of 2*count*open_chunks(log_n) u64.
+// Openings (row a9), all groups in one launch: segment g = `count` polynomials evaluated at zeta (table 0) or g*zeta (table 1);
+// results are written consecutively in segment order as interleaved (a,b) pairs. partial: scratch of
+// 2 * (total polys) * open_chunks(log_n) u64.
+struct OpenSeg { const u64* polys; size_t stride; int count; int table; int first_out; };
+struct OpenArgs { OpenSeg seg[8]; int nseg; const u64 *zp0_a, *zp0_b, *zp1_a, *zp1_b; size_t n; int chunks; };
 int open_chunks(int log_n);
-void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* partial, u64* out_ext, hipStream_t s);
+void open_polys(OpenArgs a, int log_n, u64* partial, u64* out_ext, hipStream_t s);
 
 // ---------------- FRI (fri.hip) ----------------
 struct PolyGroup { const u64* base; size_t stride; int count; };

@@ -323,11 +323,17 @@ void ext_powers(u64* out_a, u64* out_b, size_t count, Ext base, Ext scale, hipSt
   hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out_a, out_b, count, base, scale);
 }
 
-// partial[p][chunk] = sum over the chunk of polys[p][i] * zp[i]; products accumulate in 192 bits, one reduction per thread.
-__global__ void __launch_bounds__(256) k_open_partial(const u64* polys, size_t stride, size_t n, int chunks, const u64* zp_a, const u64* zp_b, u64* partial) {
+// All opening groups in one launch: segment g covers `count` polynomials (columns `stride` apart) evaluated with power table
+// `table` (0: zeta, 1: g*zeta) and writes its results at out[first_out ...]. partial[p][chunk] = sum over the chunk of
+// poly[i] * z^i; products accumulate in 192 bits with one reduction per thread.
+__global__ void __launch_bounds__(256) k_open_partial(OpenArgs a, u64* partial) {
   __shared__ u64 sa[256], sb[256];
-  const u64* p = polys + (size_t)blockIdx.x * stride;
-  const size_t per = n / chunks, lo = (size_t)blockIdx.y * per, hi = lo + per;
+  int seg = 0, local = blockIdx.x;
+  while (seg + 1 < a.nseg && local >= a.seg[seg].count) { local -= a.seg[seg].count; seg++; }
+  const OpenSeg sg = a.seg[seg];
+  const u64* p = sg.polys + (size_t)local * sg.stride;
+  const u64* zp_a = sg.table ? a.zp1_a : a.zp0_a; const u64* zp_b = sg.table ? a.zp1_b : a.zp0_b;
+  const size_t per = a.n / a.chunks, lo = (size_t)blockIdx.y * per, hi = lo + per;
   Acc192 aa{0, 0, 0}, ab{0, 0, 0};
   for (size_t i = lo + threadIdx.x; i < hi; i += 256) { u64 c = p[i]; acc_mul(aa, c, zp_a[i]); acc_mul(ab, c, zp_b[i]); }
   sa[threadIdx.x] = acc_reduce(aa); sb[threadIdx.x] = acc_reduce(ab);
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(256) k_open_partial(const u64* polys, size_t s
     if (threadIdx.x < off) { sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + off]); sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + off]); }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { size_t o = ((size_t)blockIdx.x * chunks + blockIdx.y) * 2; partial[o] = sa[0]; partial[o + 1] = sb[0]; }
+  if (threadIdx.x == 0) { size_t o = ((size_t)(sg.first_out + local) * a.chunks + blockIdx.y) * 2; partial[o] = sa[0]; partial[o + 1] = sb[0]; }
 }
 __global__ void k_open_finish(const u64* partial, int count, int chunks, u64* out_ext) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,11 +352,12 @@ __global__ void k_open_finish(const u64* partial, int count, int chunks, u64* ou
   out_ext[2 * (size_t)p] = a; out_ext[2 * (size_t)p + 1] = b;
 }
 int open_chunks(int log_n) { int c = log_n - 12; if (c < 0) c = 0; if (c > 6) c = 6; return 1 << c; }
-void open_polys(const u64* polys, size_t stride, int count, int log_n, const u64* zp_a, const u64* zp_b, u64* partial, u64* out_ext, hipStream_t s) {
-  if (count <= 0) return;
-  const int chunks = open_chunks(log_n);
-  hipLaunchKernelGGL(k_open_partial, dim3((unsigned)count, (unsigned)chunks), dim3(256), 0, s, polys, stride, size_t(1) << log_n, chunks, zp_a, zp_b, partial);
-  hipLaunchKernelGGL(k_open_finish, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, partial, count, chunks, out_ext);
+void open_polys(OpenArgs a, int log_n, u64* partial, u64* out_ext, hipStream_t s) {
+  int total = 0; for (int g = 0; g < a.nseg; g++) { a.seg[g].first_out = total; total += a.seg[g].count; }
+  if (total <= 0) return;
+  a.n = size_t(1) << log_n; a.chunks = open_chunks(log_n);
+  hipLaunchKernelGGL(k_open_partial, dim3((unsigned)total, (unsigned)a.chunks), dim3(256), 0, s, a, partial);
+  hipLaunchKernelGGL(k_open_finish, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, partial, total, a.chunks, out_ext);
 }
 
 } // namespace qp

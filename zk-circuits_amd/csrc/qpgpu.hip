@@ -127,7 +127,7 @@ static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
   if (c->split_quotient) { w->q_gate_terms = a.take((size_t)c->d.num_gate_constraints * N); w->q_perm_terms = a.take((size_t)c->nch * (2 + c->d.num_partial_products) * N); }
   w->zp0 = a.take(2 * (n + 1)); w->zp1 = a.take(2 * (n + 1)); w->zi0 = a.take(2 * (n + 1)); w->zi1 = a.take(2 * (n + 1));
   w->openings = a.take(2 * c->lay.n_openings);
-  w->open_partial = a.take(2 * (size_t)(c->S + c->W) * open_chunks(c->log_n));
+  w->open_partial = a.take(2 * c->lay.n_openings * open_chunks(c->log_n));
   w->compose_partial = a.take((size_t)FRI_COMPOSE_GROUPS * 2 * n);
   w->comp0 = a.take(2 * n); w->comp1 = a.take(2 * n); w->div_scratch = a.take(4 * n + 4 * (n / 2048 + 2)); w->pow_result = a.take(4); w->pub_counter = a.take(4);
   for (int l = 0; l <= c->nlayers; l++) w->fri_coeffs[l] = a.take((size_t)2 << c->fri_log_n[l]);
@@ -541,13 +541,15 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const Ext bases[4] = {zeta, gzeta, zinv, gzinv};
     for (int t = 0; t < 4; t++) { Ext x = bases[t]; for (int k = 0; k < pa.nbits; k++) { pa.pw[t][k] = x; x = ex_mul(x, x); } }
     ext_powers4(pa, s);
-    u64* o = w->openings;   // proof order: constants|sigmas (S), wires (W), zs (nch), zs_next (nch), pp (nch*npp), quotient (Q)
-    open_polys(c->d_cs_coeffs, n, c->S, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->S;
-    open_polys(w->wires_coeffs, n, c->W, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)c->W;
-    open_polys(w->zs_coeffs, n, nch, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)nch;
-    open_polys(w->zs_coeffs, n, nch, c->log_n, zp1a, zp1b, w->open_partial, o, s); o += 2 * (size_t)nch;
-    open_polys(w->zs_coeffs + (size_t)nch * n, n, nch * npp, c->log_n, zp0a, zp0b, w->open_partial, o, s); o += 2 * (size_t)nch * npp;
-    open_polys(w->q_vals, n, c->Q, c->log_n, zp0a, zp0b, w->open_partial, o, s);
+    // proof order: constants|sigmas (S), wires (W), zs (nch), zs_next (nch, at g*zeta), pp (nch*npp), quotient (Q)
+    OpenArgs oa; oa.nseg = 6; oa.zp0_a = zp0a; oa.zp0_b = zp0b; oa.zp1_a = zp1a; oa.zp1_b = zp1b;
+    oa.seg[0] = OpenSeg{c->d_cs_coeffs, n, c->S, 0, 0};
+    oa.seg[1] = OpenSeg{w->wires_coeffs, n, c->W, 0, 0};
+    oa.seg[2] = OpenSeg{w->zs_coeffs, n, nch, 0, 0};
+    oa.seg[3] = OpenSeg{w->zs_coeffs, n, nch, 1, 0};
+    oa.seg[4] = OpenSeg{w->zs_coeffs + (size_t)nch * n, n, nch * npp, 0, 0};
+    oa.seg[5] = OpenSeg{w->q_vals, n, c->Q, 0, 0};
+    open_polys(oa, c->log_n, w->open_partial, w->openings, s);
   }
   { int rc_ = fetch_to_host(w, s, w->openings, 2 * L.n_openings); if (rc_) return rc_; }
   mark();
