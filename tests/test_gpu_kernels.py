@@ -126,3 +126,21 @@ def test_bitrev_permute():
     out = np.zeros_like(a)
     gpu_check(qpgpu().qpgpu_test_bitrev(ptr(a), 2, 9, 1, ptr(out)))
     assert np.array_equal(out, a[:, bitrev_indices(9)])
+
+
+@pytest.mark.parametrize("log_n", [13, 14, 15, 16, 17, 18])
+def test_lde_strided_radix_path(log_n):
+    """>= 64 transforms and n >= 2^13 take the strided radix passes (register radix-2^M for 13..16, LDS radix-256 + ntt16<9/10> for
+    17/18) instead of the tiled kernel."""
+    rng = np.random.default_rng(400 + log_n)
+    n = 1 << log_n
+    cols, rate = 8, 3
+    N = n << rate
+    coeffs = rand_felts(rng, (cols, n))
+    got = np.zeros((cols, N), dtype=np.uint64)
+    gpu_check(qpgpu().qpgpu_test_lde(ptr(coeffs), cols, log_n, rate, GEN, ptr(got)))
+    rev = bitrev_indices(log_n + rate)
+    exp = np.zeros(N, dtype=np.uint64)
+    for c in (0, cols - 1):
+        oracle().orc_coset_lde(ptr(coeffs[c]), n, rate, GEN, ptr(exp))
+        assert np.array_equal(got[c], exp[rev])
