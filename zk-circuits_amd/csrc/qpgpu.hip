@@ -484,7 +484,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
   const bool split = c->split_quotient;
   commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s, [&] {
-    if (!split) return;                       // gate-constraint terms: only wires + constants, run beside the wires leaf hash
+    if (!split || getenv_int("QPGPU_SPLIT_SERIAL", 0)) return;   // gate-constraint terms: only wires + constants, run beside the wires leaf hash
     (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
     quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, w->side);
     (void)hipEventRecord(w->ev_gates, w->side);
@@ -502,7 +502,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
   values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
   commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt_seed, salts_host, s, [&] {
-    if (!split) return;                       // permutation terms: beta/gamma + Z oracle, run beside the Z leaf hash
+    if (!split || getenv_int("QPGPU_SPLIT_SERIAL", 0)) return;   // permutation terms: beta/gamma + Z oracle, run beside the Z leaf hash
     (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
     quotient_perm_terms(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->q_perm_terms, c->pl, w->side);
     (void)hipEventRecord(w->ev_perm, w->side);
@@ -516,7 +516,11 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
   alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
   { ProfScope ps(w, s, PF_QUOTIENT, 8.0 * N * (c->S + c->W + c->Zp + 2 * nch));
-    if (split) {
+    if (split && getenv_int("QPGPU_SPLIT_SERIAL", 0)) {        // diagnostic: the three split kernels back to back on the main stream
+      quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, s);
+      quotient_perm_terms(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->q_perm_terms, c->pl, s);
+      quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
+    } else if (split) {
       (void)hipStreamWaitEvent(s, w->ev_gates, 0); (void)hipStreamWaitEvent(s, w->ev_perm, 0);
       quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
     } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
