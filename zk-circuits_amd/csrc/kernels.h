@@ -95,6 +95,11 @@ void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
 void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
                    const u64* alpha_pows, int ap_stride, const u64* pi_hash /*host values*/, u64* out, const NttPlan& pl, hipStream_t s);
 
+// The fused kernel's two independent halves (part 1: L_0 + permutation terms, part 2: gate constraints) as separate launches
+// writing raw sums [nch][N]; quotient_sum adds them and divides by Z_H. Used to run both halves concurrently on two streams.
+void quotient_eval_part(int part, const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
+                        const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out_part, const NttPlan& pl, hipStream_t s);
+void quotient_sum(const CircuitDev& cd, const u64* a, const u64* b, u64* out, hipStream_t s);
 // Split form (quotient_split.hip): gate terms G [num_gate_constraints][N] need only wires/constants; permutation terms Pm
 // [nch*(2+npp)][N] need beta/gamma + the Z oracle; the combine needs alpha. Lets the first two run off the critical path.
 bool quotient_split_supported(const CircuitDev& cd);

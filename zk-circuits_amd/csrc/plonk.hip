@@ -159,6 +159,10 @@ __device__ __forceinline__ u64 sub_lazy_canon(u64 a, u64 b) { u64 d = a - b; if 
 struct Pi4 { u64 v[4]; };
 struct Zh8 { u64 zh[8]; u64 zh_inv[8]; };
 
+// PART 0: everything, output = vanishing / Z_H. PART 1: L_0 and permutation terms only, PART 2: gate constraints only; both write
+// their raw alpha-weighted sums to `out` ([nch][N]); k_quotient_sum adds the two and divides by Z_H. The halves are independent,
+// so a single proof runs them on two streams at once (each alone is only 2 waves/SIMD and stalls on its ~200-450 loads per point).
+template <int PART>
 __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __restrict__ cs, const u64* __restrict__ wl,
                                                   const u64* __restrict__ zl, Chal2 betas, Chal2 gammas,
                                                   const u64* __restrict__ apw, int ap_stride, Pi4 pih, Zh8 zh, u64 n_inv,
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
   u64 tot0 = 0, tot1 = 0;   // running sums for the two challenges
   int term = 0;
   // ---- L0(x) (Z_c(x) - 1)
-  {
+  if (PART != 2) {
     u64 zhx = zh.zh[j & ((1u << cd.rate_bits) - 1)];
     u64 l0 = gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
     for (int c = 0; c < nch; c++) {
@@ -184,28 +188,38 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
       tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
     }
   }
-  // ---- permutation checks
-  for (int c = 0; c < nch; c++) {
-    const u64 beta = betas.v[c], gamma = gammas.v[c], bx = gl_mul(beta, x);
-    u64 prev = zl[(size_t)c * N + L];
+  // ---- permutation checks: both challenges share the loads of w_j / sigma_j; factors and running products are lazy residues,
+  // the alpha-weighted terms go into one 192-bit accumulator per challenge
+  if (PART != 2) {
+    Acc192 pa[2] = {{0, 0, 0}, {0, 0, 0}};
+    u64 prev[2] = {0, 0}, bx[2] = {0, 0};
+    for (int c = 0; c < nch; c++) { prev[c] = zl[(size_t)c * N + L]; bx[c] = gl_mul(betas.v[c], x); }
     for (int k = 0; k <= npp; k++) {
-      u64 next = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
-      u64 nu = 1, de = 1;
+      u64 nu[2] = {1, 1}, de[2] = {1, 1};
       for (int jj = k * deg; jj < (k + 1) * deg && jj < R; jj++) {
-        u64 w = Wv(jj), sg = cs[(size_t)(NC + jj) * N + L];
-        nu = gl_mul(nu, gl_add(gl_add(w, gl_mul(bx, cd.k_is[jj])), gamma));
-        de = gl_mul(de, gl_add(gl_add(w, gl_mul(beta, sg)), gamma));
+        const u64 w = Wv(jj), sg = cs[(size_t)(NC + jj) * N + L], kj = cd.k_is[jj];
+        for (int c = 0; c < nch; c++) {
+          nu[c] = mul_lazy(nu[c], add_lazy_canon(add_lazy_canon(mul_lazy(bx[c], kj), w), gammas.v[c]));
+          de[c] = mul_lazy(de[c], add_lazy_canon(add_lazy_canon(mul_lazy(betas.v[c], sg), w), gammas.v[c]));
+        }
       }
-      u64 t = gl_sub(gl_mul(prev, nu), gl_mul(next, de));
-      tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
-      prev = next;
+      for (int c = 0; c < nch; c++) {
+        const u64 next = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
+        const u64 t = sub_lazy_canon(mul_lazy(prev[c], nu[c]), canon(mul_lazy(next, de[c])));
+        const int idx = term + c * (npp + 1) + k;          // every term enters BOTH alpha combinations
+        acc_mul(pa[0], t, ap0[idx]); acc_mul(pa[1], t, ap1[idx]);
+        prev[c] = next;
+      }
     }
+    tot0 = gl_add(tot0, acc_reduce(pa[0]));
+    if (nch > 1) tot1 = gl_add(tot1, acc_reduce(pa[1]));
   }
+  term = nch + nch * (npp + 1);
   // ---- gate constraints: sum_g filter_g * sum_j alpha^(term+j) c_{g,j}
   ap0 += term; ap1 += term;
   const int nsel = cd.num_selectors;
   const u64 lc0 = cs[(size_t)nsel * N + L], lc1 = cs[(size_t)(nsel + 1) * N + L];
-  for (int gi = 0; gi < cd.num_gates; gi++) {
+  for (int gi = 0; PART != 1 && gi < cd.num_gates; gi++) {
     const GateDev g = cd.gates[gi];
     const u64 sv = cs[(size_t)g.sel_index * N + L];
     u64 filter = 1;
@@ -285,18 +299,47 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
     }
     tot0 = gl_add(tot0, gl_mul(filter, acc_reduce(g0))); tot1 = gl_add(tot1, gl_mul(filter, acc_reduce(g1)));
   }
-  const u64 zi = zh.zh_inv[j & ((1u << cd.rate_bits) - 1)];
-  out[L] = gl_mul(tot0, zi);
-  if (nch > 1) out[N + L] = gl_mul(tot1, zi);
+  const u64 zi = PART == 0 ? zh.zh_inv[j & ((1u << cd.rate_bits) - 1)] : 1;
+  out[L] = PART == 0 ? gl_mul(tot0, zi) : tot0;
+  if (nch > 1) out[N + L] = PART == 0 ? gl_mul(tot1, zi) : tot1;
+}
+__global__ void __launch_bounds__(256) k_quotient_sum(int log_N, int rate_bits, int nch, const u64* __restrict__ a, const u64* __restrict__ b, Zh8 zh,
+                                                      u64* __restrict__ out) {
+  const size_t N = size_t(1) << log_N;
+  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (L >= N) return;
+  const u64 zi = zh.zh_inv[rev_bits((u32)L, log_N) & ((1u << rate_bits) - 1)];
+  for (int c = 0; c < nch; c++) out[(size_t)c * N + L] = gl_mul(gl_add(a[(size_t)c * N + L], b[(size_t)c * N + L]), zi);
 }
 
+static Zh8 quotient_zh(const CircuitDev& cd) {
+  Zh8 zh; const size_t n = size_t(1) << cd.log_n;
+  u64 gn = gl_pow(GL_GEN, n), w = gl_root(cd.rate_bits), t = 1;
+  for (int k = 0; k < 8; k++) { zh.zh[k] = 0; zh.zh_inv[k] = 0; }
+  for (int k = 0; k < (1 << cd.rate_bits) && k < 8; k++) { zh.zh[k] = gl_sub(gl_mul(gn, t), 1); zh.zh_inv[k] = gl_inv(zh.zh[k]); t = gl_mul(t, w); }
+  return zh;
+}
+// The two halves on two streams: `part` = 1 (permutation terms -> out_part) or 2 (gate terms -> out_part); then quotient_sum.
+void quotient_eval_part(int part, const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
+                        const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out_part, const NttPlan& pl, hipStream_t s) {
+  const int log_N = cd.log_n + cd.rate_bits; const size_t n = size_t(1) << cd.log_n, N = size_t(1) << log_N;
+  Pi4 pih; for (int i = 0; i < 4; i++) pih.v[i] = pi_hash[i];
+  const Zh8 zh = quotient_zh(cd);
+  dim3 grid((unsigned)((N + 255) / 256));
+  if (part == 1) hipLaunchKernelGGL(k_quotient<1>, grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
+  else hipLaunchKernelGGL(k_quotient<2>, grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
+}
+void quotient_sum(const CircuitDev& cd, const u64* a, const u64* b, u64* out, hipStream_t s) {
+  const int log_N = cd.log_n + cd.rate_bits; const size_t N = size_t(1) << log_N;
+  hipLaunchKernelGGL(k_quotient_sum, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, log_N, cd.rate_bits, cd.num_challenges, a, b, quotient_zh(cd), out);
+}
 void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
                    const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out, const NttPlan& pl, hipStream_t s) {
   const int log_N = cd.log_n + cd.rate_bits; const size_t n = size_t(1) << cd.log_n, N = size_t(1) << log_N;
   Pi4 pih; for (int i = 0; i < 4; i++) pih.v[i] = pi_hash[i];
   Zh8 zh; u64 gn = gl_pow(GL_GEN, n), w = gl_root(cd.rate_bits), t = 1;
   for (int k = 0; k < (1 << cd.rate_bits) && k < 8; k++) { zh.zh[k] = gl_sub(gl_mul(gn, t), 1); zh.zh_inv[k] = gl_inv(zh.zh[k]); t = gl_mul(t, w); }
-  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
+  hipLaunchKernelGGL(k_quotient<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
                      alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out, pl.rt, pl.log_M);
 }
 

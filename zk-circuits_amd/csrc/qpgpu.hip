@@ -155,8 +155,8 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
   int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
   e = hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, prio_hi);
   if (e != hipSuccess) { (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_HIP, "hipStreamCreate failed"); }
-  if (c->split_quotient) {
-    // the side stream carries throughput work that must not delay the latency-critical tree levels on the main stream
+  {
+    // the side stream carries work that runs beside the main stream (the quotient's second half; the opt-in split quotient)
     if (hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_lo) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&w->ev_gates, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_perm, hipEventDisableTiming) != hipSuccess) {
       ws_destroy(w); return set_err(QPGPU_ERR_HIP, "side stream / event creation failed");
@@ -523,6 +523,16 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     } else if (split) {
       (void)hipStreamWaitEvent(s, w->ev_gates, 0); (void)hipStreamWaitEvent(s, w->ev_perm, 0);
       quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
+    } else if (!w->shared_gpu && getenv_int("QPGPU_QUOTIENT_HALVES", 0)) {
+      // single proof: the permutation half and the gate half run at once on two streams (each alone offers only 2 waves/SIMD
+      // and stalls on its loads); q_lde is free until the quotient commitment and serves as scratch for the two partial sums
+      u64* pa = w->q_lde; u64* pb = w->q_lde + (size_t)nch * N;
+      (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
+      quotient_eval_part(2, c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, pb, c->pl, w->side);
+      (void)hipEventRecord(w->ev_gates, w->side);
+      quotient_eval_part(1, c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, pa, c->pl, s);
+      (void)hipStreamWaitEvent(s, w->ev_gates, 0);
+      quotient_sum(c->cd, pa, pb, w->q_vals, s);
     } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
