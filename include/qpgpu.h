@@ -35,10 +35,17 @@ typedef enum qpgpu_status {
 
 /* Gate tags = qp-plonky2's default gate-serializer ids as they appear in CommonCircuitData
  * (wormhole/bench-data/common.bin). */
-enum { QPGPU_GATE_ARITHMETIC = 0, QPGPU_GATE_BASESUM2 = 2, QPGPU_GATE_CONSTANT = 3, QPGPU_GATE_NOOP = 9,
-       QPGPU_GATE_POSEIDON = 11, QPGPU_GATE_PUBLIC_INPUT = 12 };
+enum { QPGPU_GATE_ARITHMETIC = 0, QPGPU_GATE_ARITHMETIC_EXTENSION = 1, QPGPU_GATE_BASESUM2 = 2, QPGPU_GATE_CONSTANT = 3,
+       QPGPU_GATE_COSET_INTERPOLATION = 4, QPGPU_GATE_EXPONENTIATION = 5, QPGPU_GATE_MUL_EXTENSION = 8, QPGPU_GATE_NOOP = 9,
+       QPGPU_GATE_POSEIDON_MDS = 10, QPGPU_GATE_POSEIDON = 11, QPGPU_GATE_PUBLIC_INPUT = 12, QPGPU_GATE_RANDOM_ACCESS = 13,
+       QPGPU_GATE_REDUCING_EXTENSION = 14, QPGPU_GATE_REDUCING = 15 };
 
-typedef struct qpgpu_gate { uint32_t tag; uint32_t pad; uint64_t param; } qpgpu_gate;
+/* One entry of CommonCircuitData.gates. `param` by tag: Constant num_consts; BaseSum<2> num_limbs; Arithmetic, ArithmeticExtension,
+ * MulExtension num_ops; Reducing, ReducingExtension num_coeffs; Exponentiation num_power_bits; RandomAccess bits (param2 =
+ * num_copies, param3 = num_extra_constants); CosetInterpolation subgroup_bits (param2 = degree, table = the gate's
+ * barycentric_weights[2^subgroup_bits], table_len <= 16). The leaf circuit (prove()) uses tags {0,2,3,9,11,12}; the others are the
+ * recursive-verifier circuit's gates behind aggregate() (wormhole/aggregator/src/circuits/tree.rs:106-143). */
+typedef struct qpgpu_gate { uint32_t tag; uint32_t param2; uint64_t param; uint32_t param3; uint32_t table_len; const uint64_t* table; } qpgpu_gate;
 
 /* CommonCircuitData + ProverOnlyCircuitData content the device path needs (what the reference loads with
  * WormholeProver::new_from_bytes — wormhole/prover/src/lib.rs:105-137). */

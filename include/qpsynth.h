@@ -22,11 +22,15 @@ typedef struct qpsynth_params {
   uint64_t circuit_seed;
   uint32_t fri_cap_height, fri_num_queries, fri_pow_bits;   /* 0 = preset default (4, 28, 16); pow_bits uses 0xFFFFFFFF for "0 bits" */
   uint32_t reserved;
+  /* rows of the recursive-verifier gate set (all zero: leaf gate set only), in order ArithmeticExtension, MulExtension, Reducing,
+   * ReducingExtension, RandomAccess{4}, PoseidonMds, Exponentiation, CosetInterpolation{4} — SURVEY.md App. D */
+  uint32_t n_recursion[8];
 } qpsynth_params;
 
 typedef struct qpsynth_circuit qpsynth_circuit;
 
-/* Presets: "A" leaf non-zk k=13, "B" leaf zk k=14, "V" voting-shaped k=20, "T" tiny k=6 test circuit. */
+/* Presets: "A" leaf non-zk k=13, "B" leaf zk k=14, "V" voting-shaped k=20, "T" tiny k=6 test circuit,
+ * "R" / "RT" recursion-shaped (all 14 gate types) k=13 / k=8. */
 int qpsynth_preset(const char* name, qpsynth_params* out);
 int qpsynth_circuit_create(const qpsynth_params* p, qpsynth_circuit** out);
 void qpsynth_circuit_destroy(qpsynth_circuit* c);

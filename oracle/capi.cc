@@ -82,11 +82,19 @@ int orc_transcript_pins(const uint8_t* common_b, size_t common_len, const uint8_
 }
 
 
+// gate_extra: NULL (leaf gate set) or [n_gates][ORC_GATE_EXTRA_STRIDE] u64 = {p2, p3, table_len, table[<=16]...}
+static const int ORC_GATE_EXTRA_STRIDE = 20;
+static Gate make_gate(int tag, u64 param, const u64* extra, int i) {
+  Gate g; g.tag = tag; g.param = param;
+  if (extra) { const u64* e = extra + (size_t)i * ORC_GATE_EXTRA_STRIDE; g.p2 = e[0]; g.p3 = e[1]; for (u64 k = 0; k < e[2] && k < 16; k++) g.table.push_back(e[3 + k]); }
+  return g;
+}
+
 // ---- circuit handle: CommonCircuitData fields + constants/sigmas values (the "circuit package")
 void* orc_circuit_create(int degree_bits, int num_wires, int num_routed, int num_constants, int num_challenges, int qdf,
                          int num_partial_products, int num_public_inputs, int num_gate_constraints, int zk,
                          int rate_bits, int cap_height, int num_queries, int pow_bits, int n_layers, const uint32_t* arity_bits,
-                         int n_gates, const uint32_t* gate_tags, const u64* gate_params, const uint32_t* selector_indices,
+                         int n_gates, const uint32_t* gate_tags, const u64* gate_params, const u64* gate_extra, const uint32_t* selector_indices,
                          int n_groups, const uint32_t* group_ranges, const u64* k_is, const u64* constants_sigmas,
                          const u64* digest, int threads) {
   try {
@@ -95,7 +103,7 @@ void* orc_circuit_create(int degree_bits, int num_wires, int num_routed, int num
     c.max_qdf = qdf; c.use_base_arith = true; c.zk = zk; c.rate_bits = rate_bits; c.cap_height = cap_height; c.num_queries = num_queries;
     c.pow_bits = pow_bits; for (int i = 0; i < n_layers; i++) c.arity_bits.push_back((int)arity_bits[i]);
     c.degree_bits = degree_bits; c.hiding = zk;
-    for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(Gate{(int)gate_tags[i], gate_params[i]}); }
+    for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(make_gate((int)gate_tags[i], gate_params[i], gate_extra, i)); }
     for (int i = 0; i < n_groups; i++) c.groups.push_back({(int)group_ranges[2 * i], (int)group_ranges[2 * i + 1]});
     c.qdf = qdf; c.num_gate_constraints = num_gate_constraints; c.num_constants = num_constants; c.num_public_inputs = num_public_inputs;
     c.k_is.assign(k_is, k_is + num_routed); c.num_partial_products = num_partial_products;
@@ -110,14 +118,14 @@ void* orc_circuit_create(int degree_bits, int num_wires, int num_routed, int num
 void* orc_verifier_create(int degree_bits, int num_wires, int num_routed, int num_constants, int num_challenges, int qdf,
                           int num_partial_products, int num_public_inputs, int num_gate_constraints, int zk,
                           int rate_bits, int cap_height, int num_queries, int pow_bits, int n_layers, const uint32_t* arity_bits,
-                          int n_gates, const uint32_t* gate_tags, const u64* gate_params, const uint32_t* selector_indices,
+                          int n_gates, const uint32_t* gate_tags, const u64* gate_params, const u64* gate_extra, const uint32_t* selector_indices,
                           int n_groups, const uint32_t* group_ranges, const u64* k_is, const u64* cap, const u64* digest) {
   auto* oc = new OrcCircuit(); Common& c = oc->common;
   c.num_wires = num_wires; c.num_routed = num_routed; c.cfg_num_constants = 2; c.security_bits = 100; c.num_challenges = num_challenges;
   c.max_qdf = qdf; c.use_base_arith = true; c.zk = zk; c.rate_bits = rate_bits; c.cap_height = cap_height; c.num_queries = num_queries;
   c.pow_bits = pow_bits; for (int i = 0; i < n_layers; i++) c.arity_bits.push_back((int)arity_bits[i]);
   c.degree_bits = degree_bits; c.hiding = zk;
-  for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(Gate{(int)gate_tags[i], gate_params[i]}); }
+  for (int i = 0; i < n_gates; i++) { c.selector_indices.push_back((int)selector_indices[i]); c.gates.push_back(make_gate((int)gate_tags[i], gate_params[i], gate_extra, i)); }
   for (int i = 0; i < n_groups; i++) c.groups.push_back({(int)group_ranges[2 * i], (int)group_ranges[2 * i + 1]});
   c.qdf = qdf; c.num_gate_constraints = num_gate_constraints; c.num_constants = num_constants; c.num_public_inputs = num_public_inputs;
   c.k_is.assign(k_is, k_is + num_routed); c.num_partial_products = num_partial_products;

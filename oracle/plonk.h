@@ -17,7 +17,10 @@ enum GateTag { G_ARITH = 0, G_ARITH_EXT = 1, G_BASESUM2 = 2, G_CONSTANT = 3, G_C
                G_LOOKUP = 6, G_LOOKUP_TABLE = 7, G_MUL_EXT = 8, G_NOOP = 9, G_POSEIDON_MDS = 10, G_POSEIDON = 11,
                G_PUBLIC_INPUT = 12, G_RANDOM_ACCESS = 13, G_REDUCING_EXT = 14, G_REDUCING = 15 };
 
-struct Gate { int tag; u64 param; };
+// param/p2/p3/table by gate: ArithmeticExtension, MulExtension: num_ops; Reducing, ReducingExtension: num_coeffs;
+// Exponentiation: num_power_bits; RandomAccess: (bits, num_copies, num_extra_constants); CosetInterpolation: (subgroup_bits, degree,
+// table = barycentric weights[2^subgroup_bits]).
+struct Gate { int tag; u64 param; u64 p2 = 0, p3 = 0; std::vector<u64> table; };
 
 struct Common {
   int num_wires = 0, num_routed = 0, cfg_num_constants = 0, security_bits = 0, num_challenges = 0, max_qdf = 0;

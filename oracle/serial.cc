@@ -56,6 +56,9 @@ Common parse_common(const uint8_t* b, size_t len, size_t* used) {
       case G_NOOP: case G_PUBLIC_INPUT: case G_POSEIDON: case G_POSEIDON_MDS: break;
       case G_CONSTANT: case G_BASESUM2: case G_ARITH: case G_ARITH_EXT: case G_MUL_EXT: case G_REDUCING: case G_REDUCING_EXT:
       case G_EXP: g.param = r.u64_(); break;
+      // [RECALLED field order, no golden recursion common data ships: SURVEY.md App. D]
+      case G_RANDOM_ACCESS: g.param = r.u64_(); g.p2 = r.u64_(); g.p3 = r.u64_(); break;
+      case G_COSET_INTERP: { g.param = r.u64_(); g.p2 = r.u64_(); u64 nw = r.u64_(); for (u64 k = 0; k < nw; k++) g.table.push_back(r.felt()); break; }
       default: throw std::runtime_error("gate tag not supported by oracle parser");
     }
     c.gates.push_back(g);

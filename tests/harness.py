@@ -14,7 +14,8 @@ u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 class Gate(ctypes.Structure):
-    _fields_ = [("tag", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("param", ctypes.c_uint64)]
+    _fields_ = [("tag", ctypes.c_uint32), ("param2", ctypes.c_uint32), ("param", ctypes.c_uint64), ("param3", ctypes.c_uint32),
+                ("table_len", ctypes.c_uint32), ("table", ctypes.POINTER(ctypes.c_uint64))]
 
 
 class CircuitDesc(ctypes.Structure):
@@ -31,7 +32,8 @@ class SynthParams(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint32) for k in ("degree_bits", "zero_knowledge", "n_poseidon", "n_basesum", "n_arith",
                                                "n_constant", "n_copies", "fri_num_layers")] + [
         ("fri_arity_bits", ctypes.c_uint32 * 8), ("circuit_seed", ctypes.c_uint64), ("fri_cap_height", ctypes.c_uint32),
-        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("n_recursion", ctypes.c_uint32 * 8)]
 
 
 class ProveOpts(ctypes.Structure):
@@ -64,9 +66,9 @@ def oracle():
         L.orc_hash_or_noop.argtypes = [u64p, ctypes.c_size_t, u64p]
         L.orc_proof_roundtrip.restype = ctypes.c_long
         L.orc_circuit_create.restype = ctypes.c_void_p
-        L.orc_circuit_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p, ctypes.c_int]
+        L.orc_circuit_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p, ctypes.c_int]
         L.orc_verifier_create.restype = ctypes.c_void_p
-        L.orc_verifier_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p]
+        L.orc_verifier_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p]
         L.orc_circuit_destroy.argtypes = [ctypes.c_void_p]
         L.orc_circuit_cap.argtypes = [ctypes.c_void_p, u64p]
         L.orc_prove.restype = ctypes.c_long
@@ -150,6 +152,12 @@ class OracleCircuit:
         ng = d.num_gates
         tags = np.array([d.gates[i].tag for i in range(ng)], dtype=np.uint32)
         params = np.array([d.gates[i].param for i in range(ng)], dtype=np.uint64)
+        extra = np.zeros((ng, 20), dtype=np.uint64)          # oracle/capi.cc ORC_GATE_EXTRA_STRIDE: {p2, p3, table_len, table...}
+        for i in range(ng):
+            g = d.gates[i]
+            extra[i, 0], extra[i, 1], extra[i, 2] = g.param2, g.param3, g.table_len
+            for k in range(g.table_len):
+                extra[i, 3 + k] = g.table[k]
         arity = np.array(list(d.fri_arity_bits), dtype=np.uint32)
         digest = np.array(list(d.circuit_digest), dtype=np.uint64)
         self.desc = d
@@ -159,14 +167,14 @@ class OracleCircuit:
                                            d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
                                            d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
                                            d.fri_num_queries, d.fri_pow_bits, d.fri_num_layers, ptr(arity, u32p), ng,
-                                           ptr(tags, u32p), ptr(params), d.selector_indices, d.num_selector_groups,
+                                           ptr(tags, u32p), ptr(params), ptr(extra), d.selector_indices, d.num_selector_groups,
                                            d.selector_group_ranges, d.k_is, ptr(cap), ptr(digest))
             return
         self.h = L.orc_circuit_create(d.degree_bits, d.num_wires, d.num_routed, d.num_constants, d.num_challenges,
                                       d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
                                       d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
                                       d.fri_num_queries, d.fri_pow_bits, d.fri_num_layers, ptr(arity, u32p), ng,
-                                      ptr(tags, u32p), ptr(params), d.selector_indices, d.num_selector_groups,
+                                      ptr(tags, u32p), ptr(params), ptr(extra), d.selector_indices, d.num_selector_groups,
                                       d.selector_group_ranges, d.k_is, d.constants_sigmas, ptr(digest), threads)
         if not self.h:
             raise RuntimeError(L.orc_last_error().decode())

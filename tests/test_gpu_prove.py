@@ -31,7 +31,9 @@ def circuits():
         gc.close()
 
 
-@pytest.mark.parametrize("preset", ["T", "TZ", "A", "B"])
+# "RT"/"R": recursion-shaped circuits carrying all 14 gate types of the in-circuit verifier behind aggregate()
+# (tree.rs:106-143) — parity is GPU == oracle; parity with the Rust prover is unpinned for those gates.
+@pytest.mark.parametrize("preset", ["T", "TZ", "A", "B", "RT", "R"])
 def test_proof_bytes_match_oracle(circuits, preset):
     sc, oc, gc = circuits(preset)
     assert np.array_equal(gc.cap(), oc.cap())                       # preprocessed commitment
@@ -125,7 +127,7 @@ def test_circuit_create_destroy_cycles_and_bad_descriptors():
     assert L.qpgpu_ctx_create(99, ctypes.byref(ctypes.c_void_p())) == -1
     import copy
     bad = CircuitDesc.from_buffer_copy(sc.desc)
-    bad.gates = (Gate * 6)(*[Gate(13 if i == 3 else sc.desc.gates[i].tag, 0, sc.desc.gates[i].param) for i in range(6)])   # RandomAccess: not in the leaf set
+    bad.gates = (Gate * 6)(*[Gate(6 if i == 3 else sc.desc.gates[i].tag, 0, sc.desc.gates[i].param) for i in range(6)])   # LookupGate: not supported
     h = ctypes.c_void_p()
     assert L.qpgpu_circuit_create(ctx, ctypes.byref(bad), ctypes.byref(h)) == -1 and b"not supported" in L.qpgpu_last_error()
     bad2 = CircuitDesc.from_buffer_copy(sc.desc); bad2.fri_arity_bits[0] = 7
@@ -174,3 +176,24 @@ def test_split_quotient_path_matches_oracle(monkeypatch):
             assert first_diff(gc.prove_batch([w, w], [p, p], salt_seed=21)[0], want) is None
         finally:
             gc.close()
+
+
+def test_recursion_gate_violation_is_caught_downstream(circuits):
+    """A broken recursion-gate row still yields bytes (as upstream), identical to the oracle's, and the verifier rejects them."""
+    sc, oc, gc = circuits("RT")
+    w, p = sc.witness(9)
+    pr = sc.params
+    row = 3 + pr.n_poseidon + pr.n_basesum + pr.n_arith + pr.n_constant + 2     # an ArithmeticExtension row
+    w[6, row] = (int(w[6, row]) + 1) % P
+    got = gc.prove(w, p)
+    assert first_diff(got, oc.prove(w, p)) is None and oc.verify(got) is not None
+
+
+def test_split_quotient_is_not_used_for_recursion_gates(monkeypatch):
+    monkeypatch.setenv("QPGPU_SPLIT_QUOTIENT", "1")
+    sc = SynthCircuit("RT"); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+    try:
+        w, p = sc.witness(2)
+        assert first_diff(gc.prove(w, p), oc.prove(w, p)) is None
+    finally:
+        gc.close()

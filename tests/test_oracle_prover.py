@@ -97,3 +97,55 @@ def test_oracle_prove_verify_on_varied_shapes(shape):
     assert oc.verify(pf) is None
     bad = bytearray(pf); bad[len(bad) // 2] ^= 0x10
     assert oc.verify(bytes(bad)) is not None
+
+
+# ---- recursive-verifier gate set. Layouts are the recalled upstream ones: parity with the Rust
+# prover is UNPINNED (the reference ships no aggregated proof and no recursion-circuit common data); what is checked is that the
+# base-field evaluator (prover) and the extension-algebra evaluator (verifier) agree and that every gate wire is constrained.
+REC_KINDS = ["ArithmeticExtension", "MulExtension", "Reducing", "ReducingExtension", "RandomAccess", "PoseidonMds",
+             "Exponentiation", "CosetInterpolation"]
+REC_USED_WIRES = [80, 78, 133, 132, 90, 48, 134, 47]
+
+
+@pytest.fixture(scope="module")
+def rec_tiny():
+    sc = SynthCircuit("RT"); return sc, OracleCircuit(sc.desc)
+
+
+def rec_first_row(sc, kind):
+    p = sc.params
+    return 3 + p.n_poseidon + p.n_basesum + p.n_arith + p.n_constant + sum(p.n_recursion[i] for i in range(kind))
+
+
+def test_recursion_gate_set_selectors_follow_upstream_grouping(rec_tiny):
+    sc, _ = rec_tiny
+    d = sc.desc
+    assert d.num_gates == 14 and d.num_selector_groups == 5 and d.num_constants == 7
+    assert [d.selector_group_ranges[i] for i in range(10)] == [0, 6, 6, 10, 10, 12, 12, 13, 13, 14]
+
+
+def test_recursion_gates_witness_prove_verify(rec_tiny):
+    sc, oc = rec_tiny
+    w, p = sc.witness(3)
+    assert check_witness(oc, w, p) is None
+    pf = oc.prove(w, p)
+    assert oc.verify(pf) is None
+
+
+@pytest.mark.parametrize("kind", range(8), ids=REC_KINDS)
+def test_recursion_gate_constrains_every_wire(rec_tiny, kind):
+    sc, oc = rec_tiny
+    w, p = sc.witness(4)
+    row = rec_first_row(sc, kind)
+    for col in range(REC_USED_WIRES[kind]):
+        if kind == 4 and col < 72 and col % 18 >= 2 and col % 18 - 2 != int(w[col - col % 18, row]):
+            continue                                         # RandomAccess: list items other than list[index] are free
+        w2 = w.copy(); w2[col, row] = (int(w2[col, row]) + 1) % P
+        assert check_witness(oc, w2, p) is not None, "wire %d of a %s row is unconstrained" % (col, REC_KINDS[kind])
+
+
+def test_recursion_gate_violation_gives_rejected_proof(rec_tiny):
+    sc, oc = rec_tiny
+    w, p = sc.witness(5)
+    w[9, rec_first_row(sc, 7)] = (int(w[9, rec_first_row(sc, 7)]) + 1) % P      # a CosetInterpolation value wire
+    assert oc.verify(oc.prove(w, p)) is not None

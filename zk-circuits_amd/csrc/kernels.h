@@ -73,13 +73,14 @@ static inline size_t merkle_total_digests(size_t num_leaves, int cap_height) {
 namespace qp {
 
 // ---------------- PLONK stages (plonk.hip) ----------------
-struct GateDev { u32 tag, sel_index, grp_lo, grp_hi; u64 param; };
+struct GateDev { u32 tag, sel_index, grp_lo, grp_hi; u64 param; u32 p2, p3; };
 static constexpr int MAX_GATES = 16;
 struct CircuitDev {            // passed by value to kernels
   int log_n, rate_bits, num_wires, num_routed, num_constants, num_challenges, qdf, num_pp, num_gates, num_selectors;
   int num_gate_constraints;
   GateDev gates[MAX_GATES];
   const u64* k_is;             // device, [num_routed]
+  u64 coset_w[16], coset_dom[16]; // CosetInterpolationGate: barycentric weights and the subgroup points (one such gate per circuit)
 };
 struct Chal2 { u64 v[2]; };
 

@@ -295,6 +295,113 @@ __global__ void __launch_bounds__(256) k_quotient(CircuitDev cd, const u64* __re
         for (int i = 0; i < 12; i++) { ACC_TERM(sub_lazy_canon(st[i], Wv(12 + i)), k); k++; }
         break;
       }
+      // ---- recursive-verifier circuit gates (layouts are the recalled upstream ones, parity unpinned).
+      // Extension values are pairs of base-field wires; on the coset the algebra is plain F_{p^2}.
+      case QPGPU_GATE_ARITHMETIC_EXTENSION:
+        for (u32 i = 0; i < (u32)g.param; i++) {
+          const Ext m0 = ex(Wv(8 * i), Wv(8 * i + 1)), m1 = ex(Wv(8 * i + 2), Wv(8 * i + 3)), ad = ex(Wv(8 * i + 4), Wv(8 * i + 5));
+          const Ext t = ex_sub(ex(Wv(8 * i + 6), Wv(8 * i + 7)), ex_add(ex_scale(ex_mul(m0, m1), lc0), ex_scale(ad, lc1)));
+          ACC_TERM(t.a, 2 * i); ACC_TERM(t.b, 2 * i + 1);
+        }
+        break;
+      case QPGPU_GATE_MUL_EXTENSION:
+        for (u32 i = 0; i < (u32)g.param; i++) {
+          const Ext m0 = ex(Wv(6 * i), Wv(6 * i + 1)), m1 = ex(Wv(6 * i + 2), Wv(6 * i + 3));
+          const Ext t = ex_sub(ex(Wv(6 * i + 4), Wv(6 * i + 5)), ex_scale(ex_mul(m0, m1), lc0));
+          ACC_TERM(t.a, 2 * i); ACC_TERM(t.b, 2 * i + 1);
+        }
+        break;
+      case QPGPU_GATE_REDUCING:
+      case QPGPU_GATE_REDUCING_EXTENSION: {
+        const bool xc = g.tag == QPGPU_GATE_REDUCING_EXTENSION;
+        const int nc = (int)g.param, start_accs = 6 + (xc ? 2 : 1) * nc;
+        const Ext alpha = ex(Wv(2), Wv(3));
+        Ext acc = ex(Wv(4), Wv(5));
+        for (int i = 0; i < nc; i++) {
+          const Ext coeff = xc ? ex(Wv(6 + 2 * i), Wv(7 + 2 * i)) : ex(Wv(6 + i), 0);
+          const Ext acc_i = i == nc - 1 ? ex(Wv(0), Wv(1)) : ex(Wv(start_accs + 2 * i), Wv(start_accs + 2 * i + 1));
+          const Ext t = ex_sub(ex_add(ex_mul(acc, alpha), coeff), acc_i);
+          ACC_TERM(t.a, 2 * i); ACC_TERM(t.b, 2 * i + 1);
+          acc = acc_i;
+        }
+        break;
+      }
+      case QPGPU_GATE_RANDOM_ACCESS: {
+        const int bits = (int)g.param, copies = (int)g.p2, extra = (int)g.p3, vec = 1 << bits;   // bits <= 4 (checked at creation)
+        const int routed = (2 + vec) * copies + extra;
+        int k = 0;
+        for (int c = 0; c < copies; c++) {
+          const int base = (2 + vec) * c;
+          u64 b[4], idx = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) b[i] = i < bits ? Wv(routed + c * bits + i) : 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) if (i < bits) { ACC_TERM(gl_mul(b[i], gl_sub(b[i], 1)), k); k++; }
+#pragma unroll
+          for (int i = 3; i >= 0; i--) if (i < bits) idx = gl_add(gl_add(idx, idx), b[i]);
+          ACC_TERM(gl_sub(idx, Wv(base)), k); k++;
+          u64 list[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) list[i] = i < vec ? Wv(base + 2 + i) : 0;
+#pragma unroll
+          for (int lvl = 0; lvl < 4; lvl++) if (lvl < bits) {
+#pragma unroll
+            for (int jj = 0; jj < (8 >> lvl); jj++) list[jj] = gl_add(list[2 * jj], gl_mul(b[lvl], gl_sub(list[2 * jj + 1], list[2 * jj])));
+          }
+          ACC_TERM(gl_sub(list[0], Wv(base + 1)), k); k++;
+        }
+        for (int i = 0; i < extra; i++) { ACC_TERM(gl_sub(cs[(size_t)(nsel + i) * N + L], Wv((2 + vec) * copies + i)), k); k++; }
+        break;
+      }
+      case QPGPU_GATE_POSEIDON_MDS: {
+        // the small-constant MDS acts on the two coordinates independently
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+          u64 st[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = Wv(2 * i + h);
+          mds_rc_lazy(st, nullptr);
+#pragma unroll
+          for (int i = 0; i < 12; i++) ACC_TERM(gl_sub(Wv(24 + 2 * i + h), canon(st[i])), 2 * i + h);
+        }
+        break;
+      }
+      case QPGPU_GATE_EXPONENTIATION: {
+        const int nb = (int)g.param;
+        const u64 base = Wv(0);
+        u64 prev = 1;
+        for (int i = 0; i < nb; i++) {
+          const u64 bit = Wv(1 + (nb - 1 - i)), inter = Wv(2 + nb + i);
+          ACC_TERM(gl_sub(gl_mul(prev, gl_add(gl_mul(bit, base), gl_sub(1, bit))), inter), i);
+          prev = gl_sqr(inter);
+        }
+        ACC_TERM(gl_sub(Wv(1 + nb), Wv(2 + nb + nb - 1)), nb);
+        break;
+      }
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        const int bits = (int)g.param, dg = (int)g.p2, np = 1 << bits, ni = (np - 2) / (dg - 1);
+        const int s_point = 1 + 2 * np, s_value = s_point + 2, s_inter = s_value + 2, s_shifted = s_inter + 4 * ni;
+        const Ext xs = ex(Wv(s_shifted), Wv(s_shifted + 1));
+        int k = 0;
+        { const Ext t = ex_sub(ex(Wv(s_point), Wv(s_point + 1)), ex_scale(xs, Wv(0))); ACC_TERM(t.a, k); k++; ACC_TERM(t.b, k); k++; }
+        Ext ev = ex(0), pr = ex(1);
+        int lo = 0, hi = dg;
+        for (int seg = 0; seg <= ni; seg++) {
+          for (int i = lo; i < hi; i++) {
+            const Ext term = ex(gl_sub(xs.a, cd.coset_dom[i]), xs.b);
+            const Ext val = ex_scale(ex(Wv(1 + 2 * i), Wv(2 + 2 * i)), cd.coset_w[i]);
+            ev = ex_add(ex_mul(ev, term), ex_mul(val, pr)); pr = ex_mul(pr, term);
+          }
+          if (seg == ni) break;
+          const Ext iev = ex(Wv(s_inter + 2 * seg), Wv(s_inter + 2 * seg + 1)), ipr = ex(Wv(s_inter + 2 * (ni + seg)), Wv(s_inter + 2 * (ni + seg) + 1));
+          { const Ext t = ex_sub(iev, ev); ACC_TERM(t.a, k); k++; ACC_TERM(t.b, k); k++; }
+          { const Ext t = ex_sub(ipr, pr); ACC_TERM(t.a, k); k++; ACC_TERM(t.b, k); k++; }
+          ev = iev; pr = ipr;
+          lo = 1 + (dg - 1) * (seg + 1); hi = lo + dg - 1 < np ? lo + dg - 1 : np;
+        }
+        { const Ext t = ex_sub(ex(Wv(s_value), Wv(s_value + 1)), ev); ACC_TERM(t.a, k); k++; ACC_TERM(t.b, k); k++; }
+        break;
+      }
       default: break;   // rejected at circuit creation
     }
     tot0 = gl_add(tot0, gl_mul(filter, acc_reduce(g0))); tot1 = gl_add(tot1, gl_mul(filter, acc_reduce(g1)));

@@ -85,7 +85,7 @@ struct qpgpu_circuit {
   u64* d_fri_scale[MAX_FRI_LAYERS + 1] = {nullptr};
   u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_dig = nullptr;
   std::vector<u64> cs_cap;
-  bool split_quotient = false;
+  bool split_quotient = false, leaf_gates_only = true;
   Layout lay; size_t ws_bytes = 0;
   std::mutex mu; std::vector<Workspace*> free_ws;
 };
@@ -298,8 +298,32 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
     if (sum > d.degree_bits) return set_err(QPGPU_ERR_ARG, "FRI reductions exceed degree"); }
   for (uint32_t i = 0; i < d.num_gates; i++) {
     uint32_t t = d.gates[i].tag;
-    bool ok = t == QPGPU_GATE_NOOP || t == QPGPU_GATE_CONSTANT || t == QPGPU_GATE_PUBLIC_INPUT || t == QPGPU_GATE_BASESUM2 || t == QPGPU_GATE_ARITHMETIC || t == QPGPU_GATE_POSEIDON;
-    if (!ok) return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(t) + " is not supported by this backend (leaf-circuit gate set only)");
+    const qpgpu_gate& gt = d.gates[i];
+    const uint64_t W = d.num_wires, Rt = d.num_routed;
+    switch (t) {
+      case QPGPU_GATE_NOOP: case QPGPU_GATE_CONSTANT: case QPGPU_GATE_PUBLIC_INPUT: case QPGPU_GATE_BASESUM2: case QPGPU_GATE_ARITHMETIC: case QPGPU_GATE_POSEIDON: break;
+      case QPGPU_GATE_ARITHMETIC_EXTENSION: if (8 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "ArithmeticExtension ops exceed routed wires"); break;
+      case QPGPU_GATE_MUL_EXTENSION: if (6 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "MulExtension ops exceed routed wires"); break;
+      case QPGPU_GATE_REDUCING: if (gt.param < 1 || 6 + 3 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "Reducing coefficients exceed wires"); break;
+      case QPGPU_GATE_REDUCING_EXTENSION: if (gt.param < 1 || 6 + 4 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "ReducingExtension coefficients exceed wires"); break;
+      case QPGPU_GATE_RANDOM_ACCESS: {
+        if (gt.param < 1 || gt.param > 4) return set_err(QPGPU_ERR_ARG, "RandomAccess bits must be 1..4");
+        uint64_t vec = 1ull << gt.param, routed = (2 + vec) * gt.param2 + gt.param3;
+        if (routed > Rt || routed + gt.param * gt.param2 > W || gt.param3 + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "RandomAccess copies exceed wires/constants");
+        break;
+      }
+      case QPGPU_GATE_POSEIDON_MDS: if (W < 48) return set_err(QPGPU_ERR_ARG, "PoseidonMds gate needs 48 wires"); break;
+      case QPGPU_GATE_EXPONENTIATION: if (gt.param < 1 || 2 + 2 * gt.param > W) return set_err(QPGPU_ERR_ARG, "Exponentiation bits exceed wires"); break;
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        if (gt.param < 1 || gt.param > 4 || gt.param2 < 2 || !gt.table || gt.table_len != (1u << gt.param)) return set_err(QPGPU_ERR_ARG, "CosetInterpolation needs subgroup_bits 1..4, degree >= 2 and 2^bits weights");
+        uint64_t np = 1ull << gt.param, ni = (np - 2) / (gt.param2 - 1);
+        if (1 + 2 * np + 4 + 4 * ni + 2 > W) return set_err(QPGPU_ERR_ARG, "CosetInterpolation exceeds wires");
+        for (uint32_t k = 0; k < gt.table_len; k++) if (gt.table[k] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical barycentric weight");
+        for (uint32_t j = 0; j < i; j++) if (d.gates[j].tag == QPGPU_GATE_COSET_INTERPOLATION) return set_err(QPGPU_ERR_ARG, "one CosetInterpolation gate per circuit");
+        break;
+      }
+      default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(t) + " is not supported by this backend (lookup gates)");
+    }
     if (d.selector_indices[i] >= d.num_selector_groups) return set_err(QPGPU_ERR_ARG, "selector index out of range");
     if (t == QPGPU_GATE_POSEIDON && d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires");
     if (t == QPGPU_GATE_BASESUM2 && d.gates[i].param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires");
@@ -309,7 +333,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   HIP_TRY(hipSetDevice(ctx->device));
   qpgpu_circuit* c = new qpgpu_circuit();
   c->ctx = ctx; c->device = ctx->device; c->d = d;
-  c->gates.assign(d.gates, d.gates + d.num_gates); c->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
+  c->gates.assign(d.gates, d.gates + d.num_gates); for (auto& g : c->gates) g.table = nullptr;   /* weights live in cd.coset_w */ c->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
   c->groups.assign(d.selector_group_ranges, d.selector_group_ranges + 2 * d.num_selector_groups);
   c->k_is_h.assign(d.k_is, d.k_is + d.num_routed);
   c->d.gates = c->gates.data(); c->d.selector_indices = c->sel_idx.data(); c->d.selector_group_ranges = c->groups.data();
@@ -362,7 +386,14 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   c->cd.num_selectors = d.num_selector_groups; c->cd.num_gate_constraints = d.num_gate_constraints; c->cd.k_is = c->d_kis;
   for (uint32_t i = 0; i < d.num_gates; i++) {
     uint32_t si = d.selector_indices[i];
-    c->cd.gates[i] = GateDev{d.gates[i].tag, si, d.selector_group_ranges[2 * si], d.selector_group_ranges[2 * si + 1], d.gates[i].param};
+    c->cd.gates[i] = GateDev{d.gates[i].tag, si, d.selector_group_ranges[2 * si], d.selector_group_ranges[2 * si + 1], d.gates[i].param, d.gates[i].param2, d.gates[i].param3};
+    if (d.gates[i].tag == QPGPU_GATE_COSET_INTERPOLATION) {
+      const u64 wg = gl_root((int)d.gates[i].param); u64 x = 1;
+      for (uint32_t k = 0; k < d.gates[i].table_len; k++) { c->cd.coset_w[k] = d.gates[i].table[k]; c->cd.coset_dom[k] = x; x = gl_mul(x, wg); }
+    }
+    const uint32_t t = d.gates[i].tag;
+    if (!(t == QPGPU_GATE_NOOP || t == QPGPU_GATE_CONSTANT || t == QPGPU_GATE_PUBLIC_INPUT || t == QPGPU_GATE_BASESUM2 || t == QPGPU_GATE_ARITHMETIC || t == QPGPU_GATE_POSEIDON))
+      c->leaf_gates_only = false;
   }
   // preprocessed oracle: constants/sigmas values -> coeffs -> LDE -> Merkle (kept resident)
   CC_TRY(hipMalloc((void**)&c->d_cs_vals, (size_t)c->S * n * 8));
@@ -378,7 +409,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   nows->pev_used = 0; ws_destroy(nows);
   CC_TRY(hipGetLastError());
   { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
-  c->split_quotient = quotient_split_supported(c->cd);
+  c->split_quotient = quotient_split_supported(c->cd) && c->leaf_gates_only;
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
   *out = c; return 0;
 }
@@ -428,13 +459,24 @@ int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* d, 
   d->num_partial_products = (uint32_t)r.u64_();
   uint64_t nlp = r.u64_(), nls = r.u64_(), nluts = r.u64_();
   if (nlp || nls || nluts) return set_err(QPGPU_ERR_ARG, "lookup arguments are not supported by this backend");
+  uint64_t tables_used = 0;
   uint64_t ngates = r.u64_(); if (ngates > gates_cap || ngates != ns) return set_err(QPGPU_ERR_ARG, "gate count mismatch");
   for (uint64_t i = 0; i < ngates && r.ok; i++) {
-    gates[i].tag = r.u32_(); gates[i].pad = 0; gates[i].param = 0;
+    memset(&gates[i], 0, sizeof gates[i]); gates[i].tag = r.u32_();
     switch (gates[i].tag) {
-      case QPGPU_GATE_NOOP: case QPGPU_GATE_PUBLIC_INPUT: case QPGPU_GATE_POSEIDON: break;
-      case QPGPU_GATE_CONSTANT: case QPGPU_GATE_BASESUM2: case QPGPU_GATE_ARITHMETIC: gates[i].param = r.u64_(); break;
-      default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(gates[i].tag) + " is outside the leaf-circuit gate set");
+      case QPGPU_GATE_NOOP: case QPGPU_GATE_PUBLIC_INPUT: case QPGPU_GATE_POSEIDON: case QPGPU_GATE_POSEIDON_MDS: break;
+      case QPGPU_GATE_CONSTANT: case QPGPU_GATE_BASESUM2: case QPGPU_GATE_ARITHMETIC: case QPGPU_GATE_ARITHMETIC_EXTENSION: case QPGPU_GATE_MUL_EXTENSION:
+      case QPGPU_GATE_REDUCING: case QPGPU_GATE_REDUCING_EXTENSION: case QPGPU_GATE_EXPONENTIATION: gates[i].param = r.u64_(); break;
+      // field order of the two multi-parameter gates is recalled, not pinned by any shipped artefact
+      case QPGPU_GATE_RANDOM_ACCESS: gates[i].param = r.u64_(); gates[i].param2 = (uint32_t)r.u64_(); gates[i].param3 = (uint32_t)r.u64_(); break;
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        gates[i].param = r.u64_(); gates[i].param2 = (uint32_t)r.u64_(); uint64_t nw = r.u64_();
+        if (nw > 16 || nk + tables_used + nw > k_is_cap) return set_err(QPGPU_ERR_ARG, "barycentric weights exceed the k_is buffer tail");
+        gates[i].table = k_is + nk + tables_used; gates[i].table_len = (uint32_t)nw;
+        for (uint64_t k = 0; k < nw; k++) k_is[nk + tables_used + k] = r.u64_();
+        tables_used += nw; break;
+      }
+      default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(gates[i].tag) + " is not supported (lookup gates)");
     }
   }
   d->num_gates = (uint32_t)ngates;

@@ -15,7 +15,8 @@ class QpgpuError(RuntimeError):
 
 
 class Gate(ctypes.Structure):
-    _fields_ = [("tag", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("param", ctypes.c_uint64)]
+    _fields_ = [("tag", ctypes.c_uint32), ("param2", ctypes.c_uint32), ("param", ctypes.c_uint64), ("param3", ctypes.c_uint32),
+                ("table_len", ctypes.c_uint32), ("table", ctypes.POINTER(ctypes.c_uint64))]
 
 
 class CircuitDesc(ctypes.Structure):
@@ -32,7 +33,8 @@ class SynthParams(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint32) for k in ("degree_bits", "zero_knowledge", "n_poseidon", "n_basesum", "n_arith",
                                                "n_constant", "n_copies", "fri_num_layers")] + [
         ("fri_arity_bits", ctypes.c_uint32 * 8), ("circuit_seed", ctypes.c_uint64), ("fri_cap_height", ctypes.c_uint32),
-        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("n_recursion", ctypes.c_uint32 * 8)]
 
 
 class ProveOpts(ctypes.Structure):

@@ -21,9 +21,26 @@ struct Rng {  // SplitMix64
   u64 below(u64 n) { return next() % n; }
 };
 
-enum RowKind : uint8_t { K_NOOP = 0, K_CONST = 1, K_PI = 2, K_BASESUM = 3, K_ARITH = 4, K_POSEIDON = 5 };
-const int W = 135, R = 80, NC = 4, NPI = 16;
-const int GATE_INDEX[6] = {0, 1, 2, 3, 4, 5};  // list position of [Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon]
+enum RowKind : uint8_t { K_NOOP = 0, K_CONST = 1, K_PI = 2, K_BASESUM = 3, K_ARITH = 4, K_POSEIDON = 5,
+                         // recursive-verifier gate set (qpsynth_params.n_recursion[])
+                         K_ARITH_EXT = 6, K_MUL_EXT = 7, K_REDUCING = 8, K_REDUCING_EXT = 9, K_RANDOM_ACCESS = 10, K_POSEIDON_MDS = 11,
+                         K_EXP = 12, K_COSET = 13, K_KINDS = 14 };
+const int W = 135, R = 80, NPI = 16;
+// per kind: serializer tag, parameters under standard_recursion_config (135 wires / 80 routed / D = 2), constraint degree
+struct KindInfo { uint32_t tag; uint64_t param; uint32_t p2, p3; int degree; };
+const KindInfo KINDS[K_KINDS] = {
+  {QPGPU_GATE_NOOP, 0, 0, 0, 0}, {QPGPU_GATE_CONSTANT, 2, 0, 0, 1}, {QPGPU_GATE_PUBLIC_INPUT, 0, 0, 0, 1}, {QPGPU_GATE_BASESUM2, 63, 0, 0, 2},
+  {QPGPU_GATE_ARITHMETIC, 20, 0, 0, 3}, {QPGPU_GATE_POSEIDON, 0, 0, 0, 7},
+  {QPGPU_GATE_ARITHMETIC_EXTENSION, 10, 0, 0, 3}, {QPGPU_GATE_MUL_EXTENSION, 13, 0, 0, 3}, {QPGPU_GATE_REDUCING, 43, 0, 0, 2},
+  {QPGPU_GATE_REDUCING_EXTENSION, 32, 0, 0, 2}, {QPGPU_GATE_RANDOM_ACCESS, 4, 4, 2, 5}, {QPGPU_GATE_POSEIDON_MDS, 0, 0, 0, 1},
+  {QPGPU_GATE_EXPONENTIATION, 66, 0, 0, 4}, {QPGPU_GATE_COSET_INTERPOLATION, 4, 6, 0, 6}};
+const int COSET_BITS = 4, COSET_DEG = 6, COSET_NP = 16, COSET_NI = (COSET_NP - 2) / (COSET_DEG - 1);
+
+struct E2 { u64 a, b; };   // F_{p^2} = F_p[X]/(X^2 - 7)
+inline E2 e_add(E2 x, E2 y) { return {gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
+inline E2 e_sub(E2 x, E2 y) { return {gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }
+inline E2 e_mul(E2 x, E2 y) { return {gl_add(gl_mul(x.a, y.a), gl_mul(7, gl_mul(x.b, y.b))), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a))}; }
+inline E2 e_scale(E2 x, u64 k) { return {gl_mul(x.a, k), gl_mul(x.b, k)}; }
 
 struct Cell { uint32_t row; uint16_t col; };
 } // namespace
@@ -35,6 +52,9 @@ struct qpsynth_circuit {
   std::vector<u64> constants_sigmas;         // [84][n]
   std::vector<u64> k_is;
   std::vector<qpgpu_gate> gates; std::vector<uint32_t> sel_idx, groups;
+  int nsel = 2, NC = 4;                      // selector columns, total constant columns (selectors + 2)
+  int gate_index[K_KINDS];                   // position of each row kind's gate in the gate list (-1: absent)
+  std::vector<u64> coset_weights, coset_dom;
   // copy constraints, in application order: value[tgt] = value[src]
   std::vector<Cell> copy_src, copy_tgt;      // phase-2 (arith inputs) first, then phase-3 (free cells)
   size_t n_phase2 = 0;
@@ -66,6 +86,16 @@ int qpsynth_preset(const char* name, qpsynth_params* o) {
   } else if (s == "TZ") {
     o->degree_bits = 7; o->zero_knowledge = 1; o->n_poseidon = 6; o->n_basesum = 12; o->n_arith = 16; o->n_constant = 3; o->n_copies = 150;
     o->fri_num_layers = 1; o->fri_arity_bits[0] = 4; o->circuit_seed = 0x5157C1C0ULL + 7;
+  } else if (s == "R" || s == "RT") {
+    // recursion-shaped: every gate of the in-circuit verifier (aggregate(), tree.rs:106-143) next to the leaf set
+    const bool tiny = s == "RT";
+    o->degree_bits = tiny ? 8 : 13; o->zero_knowledge = 0;
+    uint32_t m = tiny ? 1 : 40;
+    o->n_poseidon = 12 * m; o->n_basesum = 8 * m; o->n_arith = 12 * m; o->n_constant = 3 * m; o->n_copies = 300 * m;
+    const uint32_t rec[8] = {20 * m, 12 * m, 20 * m, 12 * m, 16 * m, 6 * m, 6 * m, 8 * m};
+    for (int i = 0; i < 8; i++) o->n_recursion[i] = rec[i];
+    o->fri_num_layers = tiny ? 1 : 2; for (int i = 0; i < 2; i++) o->fri_arity_bits[i] = 4;
+    o->circuit_seed = 0x5157C1C0ULL + 0x100 + o->degree_bits;
   } else return fail("unknown preset");
   return 0;
 }
@@ -76,7 +106,8 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   const qpsynth_params& p = c->p;
   if (p.degree_bits < 5 || p.degree_bits > 24) { delete c; return fail("degree_bits out of range"); }
   size_t n = c->n = size_t(1) << p.degree_bits;
-  size_t used = 3 + (size_t)p.n_poseidon + p.n_basesum + p.n_arith + p.n_constant;
+  size_t n_rec = 0; for (int i = 0; i < 8; i++) n_rec += p.n_recursion[i];
+  size_t used = 3 + (size_t)p.n_poseidon + p.n_basesum + p.n_arith + p.n_constant + n_rec;
   if (used > n) { delete c; return fail("gate rows exceed 2^degree_bits"); }
   { int sum = 0; for (uint32_t i = 0; i < p.fri_num_layers; i++) sum += p.fri_arity_bits[i]; if (p.fri_num_layers > 8 || sum > (int)p.degree_bits) { delete c; return fail("bad FRI arities"); } }
   Rng rng(p.circuit_seed);
@@ -89,6 +120,33 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   for (uint32_t i = 0; i < p.n_basesum; i++) c->kind[r++] = K_BASESUM;
   for (uint32_t i = 0; i < p.n_arith; i++) c->kind[r++] = K_ARITH;
   for (uint32_t i = 0; i < p.n_constant; i++) c->kind[r++] = K_CONST;
+  for (int k = 0; k < 8; k++) for (uint32_t i = 0; i < p.n_recursion[k]; i++) c->kind[r++] = (uint8_t)(K_ARITH_EXT + k);
+  // ---- gate list: kinds in use, ordered by constraint degree; selector groups as upstream forms them
+  // (a group grows while group_size + next_gate_degree < max_degree = 8). The leaf set gives [0,5),[5,6) as in common.bin.
+  {
+    std::vector<int> kinds;
+    for (int k = 0; k < K_KINDS; k++) if (k <= K_POSEIDON || (n_rec && p.n_recursion[k - K_ARITH_EXT])) kinds.push_back(k);
+    std::stable_sort(kinds.begin(), kinds.end(), [](int a, int b) { return KINDS[a].degree < KINDS[b].degree; });
+    for (int k = 0; k < K_KINDS; k++) c->gate_index[k] = -1;
+    for (size_t i = 0; i < kinds.size(); i++) c->gate_index[kinds[i]] = (int)i;
+    if (kinds.size() > 16) { delete c; return fail("too many gates"); }
+    { u64 wg = gl_root(COSET_BITS), x = 1; for (int i = 0; i < COSET_NP; i++) { c->coset_dom.push_back(x); x = gl_mul(x, wg); } }
+    for (int i = 0; i < COSET_NP; i++) { u64 d = 1; for (int j = 0; j < COSET_NP; j++) if (j != i) d = gl_mul(d, gl_sub(c->coset_dom[i], c->coset_dom[j])); c->coset_weights.push_back(gl_inv(d)); }
+    size_t start = 0; c->sel_idx.assign(kinds.size(), 0);
+    while (start < kinds.size()) {
+      size_t size = 0;
+      while (start + size < kinds.size() && (int)size + KINDS[kinds[start + size]].degree < 8) size++;
+      for (size_t i = 0; i < size; i++) c->sel_idx[start + i] = (uint32_t)(c->groups.size() / 2);
+      c->groups.push_back((uint32_t)start); c->groups.push_back((uint32_t)(start + size)); start += size;
+    }
+    for (int k : kinds) {
+      qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = KINDS[k].tag; g.param = KINDS[k].param; g.param2 = KINDS[k].p2; g.param3 = KINDS[k].p3;
+      if (k == K_COSET) { g.table = c->coset_weights.data(); g.table_len = COSET_NP; }
+      c->gates.push_back(g);
+    }
+    c->nsel = (int)(c->groups.size() / 2); c->NC = c->nsel + 2;
+  }
+  const int NC = c->NC, nsel = c->nsel;
 
   c->k_is.resize(R); { u64 x = 1; for (int j = 0; j < R; j++) { c->k_is[j] = x; x = gl_mul(x, GL_GEN); } }
   c->constants_sigmas.assign((size_t)(NC + R) * n, 0);
@@ -96,10 +154,13 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   const u64 UNUSED = 0xFFFFFFFFULL;
   for (size_t i = 0; i < n; i++) {
     int k = c->kind[i];
-    cs[0 * n + i] = k == K_POSEIDON ? UNUSED : (u64)GATE_INDEX[k];
-    cs[1 * n + i] = k == K_POSEIDON ? (u64)GATE_INDEX[K_POSEIDON] : UNUSED;
-    if (k == K_ARITH) { u64 t = rng.below(4); cs[2 * n + i] = t == 0 ? 1 : (t == 1 ? rng.below(1 << 16) : rng.felt()); cs[3 * n + i] = rng.below(3) == 0 ? rng.felt() : 1; }
-    if (k == K_CONST) { cs[2 * n + i] = rng.felt(); cs[3 * n + i] = rng.felt(); }
+    const int gi = c->gate_index[k];
+    for (int sc = 0; sc < nsel; sc++) cs[(size_t)sc * n + i] = (int)c->sel_idx[gi] == sc ? (u64)gi : UNUSED;
+    u64* lc0 = &cs[(size_t)nsel * n + i]; u64* lc1 = &cs[(size_t)(nsel + 1) * n + i];
+    if (k == K_ARITH) { u64 t = rng.below(4); *lc0 = t == 0 ? 1 : (t == 1 ? rng.below(1 << 16) : rng.felt()); *lc1 = rng.below(3) == 0 ? rng.felt() : 1; }
+    if (k == K_CONST) { *lc0 = rng.felt(); *lc1 = rng.felt(); }
+    if (k == K_ARITH_EXT || k == K_MUL_EXT) { *lc0 = rng.below(2) ? 1 : rng.felt(); *lc1 = rng.below(2) ? 1 : rng.felt(); }
+    if (k == K_RANDOM_ACCESS) { *lc0 = rng.felt(); *lc1 = rng.felt(); }
   }
   // ---- copy constraints. sigma as a permutation over routed cells (col*n + row), built by cycle splicing.
   std::vector<uint32_t> sigma((size_t)R * n);
@@ -150,8 +211,6 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
     for (size_t i = 0; i < n; i++) { wpow[i] = x; x = gl_mul(x, w); }
     for (int j = 0; j < R; j++) for (size_t i = 0; i < n; i++) { uint32_t t = sigma[(size_t)j * n + i]; cs[(size_t)(NC + j) * n + i] = gl_mul(c->k_is[t / n], wpow[t % n]); }
   }
-  c->gates = {{QPGPU_GATE_NOOP, 0, 0}, {QPGPU_GATE_CONSTANT, 0, 2}, {QPGPU_GATE_PUBLIC_INPUT, 0, 0}, {QPGPU_GATE_BASESUM2, 0, 63}, {QPGPU_GATE_ARITHMETIC, 0, 20}, {QPGPU_GATE_POSEIDON, 0, 0}};
-  c->sel_idx = {0, 0, 0, 0, 0, 1}; c->groups = {0, 5, 5, 6};
   qpgpu_circuit_desc& d = c->desc; memset(&d, 0, sizeof d);
   d.degree_bits = p.degree_bits; d.num_wires = W; d.num_routed = R; d.num_constants = NC; d.num_challenges = 2;
   d.quotient_degree_factor = 8; d.num_partial_products = 9; d.num_public_inputs = NPI; d.num_gate_constraints = 123;
@@ -160,10 +219,12 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   d.fri_num_queries = p.fri_num_queries ? p.fri_num_queries : 28;
   d.fri_pow_bits = p.fri_pow_bits == 0xFFFFFFFFu ? 0 : (p.fri_pow_bits ? p.fri_pow_bits : 16);
   d.fri_num_layers = p.fri_num_layers; for (int i = 0; i < 8; i++) d.fri_arity_bits[i] = p.fri_arity_bits[i];
-  d.num_gates = 6; d.num_selector_groups = 2; d.gates = c->gates.data(); d.selector_indices = c->sel_idx.data();
+  d.num_gates = (uint32_t)c->gates.size(); d.num_selector_groups = (uint32_t)nsel; d.gates = c->gates.data(); d.selector_indices = c->sel_idx.data();
   d.selector_group_ranges = c->groups.data(); d.k_is = c->k_is.data(); d.constants_sigmas = cs;
   // Synthetic digest (the real one hashes the constants/sigmas cap + common data; any 4 felts serve the transcript).
-  { u64 t[8] = {p.circuit_seed % GL_P, p.degree_bits, p.zero_knowledge, p.n_poseidon, p.n_basesum, p.n_arith, p.n_constant, p.n_copies}; hash_no_pad(t, 8, d.circuit_digest); }
+  { u64 t[16] = {p.circuit_seed % GL_P, p.degree_bits, p.zero_knowledge, p.n_poseidon, p.n_basesum, p.n_arith, p.n_constant, p.n_copies};
+    for (int i = 0; i < 8; i++) t[8 + i] = p.n_recursion[i];
+    hash_no_pad(t, n_rec ? 16 : 8, d.circuit_digest); }
   *out = c; return 0;
 }
 
@@ -207,7 +268,11 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
   Rng rng(seed * 0xD1B54A32D192ED03ULL + 0x5157);
   memset(wires, 0, sizeof(u64) * (size_t)W * n);
   const u64* cs = c->constants_sigmas.data();
+  const int nsel = c->nsel;
   auto Wr = [&](size_t row, int col) -> u64& { return wires[(size_t)col * n + row]; };
+  auto LC = [&](size_t row, int i) -> u64 { return cs[(size_t)(nsel + i) * n + row]; };
+  auto rext = [&]() -> E2 { E2 e; e.a = rng.felt(); e.b = rng.felt(); return e; };
+  auto putx = [&](size_t row, int col, E2 v) { Wr(row, col) = v.a; Wr(row, col + 1) = v.b; };
   for (int i = 0; i < NPI; i++) public_inputs[i] = rng.felt();
   // PI hash rows
   { u64 in[12] = {0}; for (int i = 0; i < 8; i++) in[i] = public_inputs[i]; poseidon_row(wires, n, c->row_h0, in, 0);
@@ -219,7 +284,79 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
     switch (c->kind[row]) {
       case K_POSEIDON: { u64 in[12]; for (auto& x : in) x = rng.felt(); poseidon_row(wires, n, row, in, rng.next() & 1); break; }
       case K_BASESUM: { u64 v = rng.next() >> 1; Wr(row, 0) = v; for (int l = 0; l < 63; l++) Wr(row, 1 + l) = (v >> l) & 1; break; }
-      case K_CONST: Wr(row, 0) = cs[2 * n + row]; Wr(row, 1) = cs[3 * n + row]; break;
+      case K_CONST: Wr(row, 0) = LC(row, 0); Wr(row, 1) = LC(row, 1); break;
+      case K_ARITH_EXT:
+        for (int op = 0; op < 10; op++) {
+          E2 m0 = rext(), m1 = rext(), ad = rext();
+          putx(row, 8 * op, m0); putx(row, 8 * op + 2, m1); putx(row, 8 * op + 4, ad);
+          putx(row, 8 * op + 6, e_add(e_scale(e_mul(m0, m1), LC(row, 0)), e_scale(ad, LC(row, 1))));
+        }
+        break;
+      case K_MUL_EXT:
+        for (int op = 0; op < 13; op++) {
+          E2 m0 = rext(), m1 = rext();
+          putx(row, 6 * op, m0); putx(row, 6 * op + 2, m1); putx(row, 6 * op + 4, e_scale(e_mul(m0, m1), LC(row, 0)));
+        }
+        break;
+      case K_REDUCING: case K_REDUCING_EXT: {
+        const bool xc = c->kind[row] == K_REDUCING_EXT; const int nc = xc ? 32 : 43, start_accs = 6 + (xc ? 2 : 1) * nc;
+        E2 alpha = rext(), acc = rext();
+        putx(row, 2, alpha); putx(row, 4, acc);
+        for (int i = 0; i < nc; i++) {
+          E2 coeff; if (xc) { coeff = rext(); putx(row, 6 + 2 * i, coeff); } else { coeff.a = rng.felt(); coeff.b = 0; Wr(row, 6 + i) = coeff.a; }
+          acc = e_add(e_mul(acc, alpha), coeff);
+          putx(row, i == nc - 1 ? 0 : start_accs + 2 * i, acc);
+        }
+        break;
+      }
+      case K_RANDOM_ACCESS:
+        for (int cp = 0; cp < 4; cp++) {
+          const int base = 18 * cp; u64 idx = rng.below(16);
+          Wr(row, base) = idx;
+          for (int i = 0; i < 16; i++) Wr(row, base + 2 + i) = rng.felt();
+          Wr(row, base + 1) = Wr(row, base + 2 + (int)idx);
+          for (int i = 0; i < 4; i++) Wr(row, 74 + 4 * cp + i) = (idx >> i) & 1;
+        }
+        Wr(row, 72) = LC(row, 0); Wr(row, 73) = LC(row, 1);
+        break;
+      case K_POSEIDON_MDS: {
+        u64 a[12], b[12];
+        for (int i = 0; i < 12; i++) { a[i] = rng.felt(); b[i] = rng.felt(); Wr(row, 2 * i) = a[i]; Wr(row, 2 * i + 1) = b[i]; }
+        mds_layer(a); mds_layer(b);
+        for (int i = 0; i < 12; i++) { Wr(row, 24 + 2 * i) = a[i]; Wr(row, 24 + 2 * i + 1) = b[i]; }
+        break;
+      }
+      case K_EXP: {
+        const int nb = 66; u64 base = rng.felt(), prev = 1;
+        Wr(row, 0) = base;
+        for (int i = 0; i < nb; i++) Wr(row, 1 + i) = rng.next() & 1;
+        for (int i = 0; i < nb; i++) {
+          u64 v = gl_mul(prev, Wr(row, 1 + (nb - 1 - i)) ? base : 1);
+          Wr(row, 2 + nb + i) = v; prev = gl_mul(v, v);
+        }
+        Wr(row, 1 + nb) = Wr(row, 2 + nb + nb - 1);
+        break;
+      }
+      case K_COSET: {
+        const int s_point = 1 + 2 * COSET_NP, s_value = s_point + 2, s_inter = s_value + 2, s_shifted = s_inter + 4 * COSET_NI;
+        u64 shift = rng.felt(); if (shift == 0) shift = 1;
+        E2 vals[COSET_NP], point = rext(), xs = e_scale(point, gl_inv(shift));
+        Wr(row, 0) = shift; putx(row, s_point, point); putx(row, s_shifted, xs);
+        for (int i = 0; i < COSET_NP; i++) { vals[i] = rext(); putx(row, 1 + 2 * i, vals[i]); }
+        E2 ev{0, 0}, pr{1, 0};
+        int lo = 0, hi = COSET_DEG;
+        for (int seg = 0; seg <= COSET_NI; seg++) {
+          for (int i = lo; i < hi; i++) {
+            E2 term{gl_sub(xs.a, c->coset_dom[i]), xs.b};
+            ev = e_add(e_mul(ev, term), e_mul(e_scale(vals[i], c->coset_weights[i]), pr)); pr = e_mul(pr, term);
+          }
+          if (seg == COSET_NI) break;
+          putx(row, s_inter + 2 * seg, ev); putx(row, s_inter + 2 * (COSET_NI + seg), pr);
+          lo = 1 + (COSET_DEG - 1) * (seg + 1); hi = std::min(lo + COSET_DEG - 1, COSET_NP);
+        }
+        putx(row, s_value, ev);
+        break;
+      }
       default: break;
     }
   }
@@ -235,7 +372,7 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
   // phase 2: copies into arithmetic inputs (first 8 entries are the PI-hash wiring, already consistent)
   for (size_t k = 8; k < c->n_phase2; k++) Wr(c->copy_tgt[k].row, c->copy_tgt[k].col) = Wr(c->copy_src[k].row, c->copy_src[k].col);
   for (size_t row = 3; row < n; row++) if (c->kind[row] == K_ARITH) {
-    u64 c0 = cs[2 * n + row], c1 = cs[3 * n + row];
+    u64 c0 = LC(row, 0), c1 = LC(row, 1);
     for (int op = 0; op < 20; op++) Wr(row, 4 * op + 3) = gl_add(gl_mul(c0, gl_mul(Wr(row, 4 * op), Wr(row, 4 * op + 1))), gl_mul(c1, Wr(row, 4 * op + 2)));
   }
   // phase 3: copies into free cells
