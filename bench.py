@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--preset", default="B", help="A: leaf non-zk 2^13, B: leaf zk 2^14 (default), V: voting-shaped 2^20")
+    ap.add_argument("--preset", default="B", help="A: leaf non-zk 2^13, B: leaf zk 2^14 (default), V: voting-shaped 2^20, R: recursion-shaped 2^13")
     ap.add_argument("--batch", type=int, default=1, help=">1: each step is one stream-pipelined batch (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra (untimed-headline) stream-pipelined throughput measurement")
@@ -189,19 +189,30 @@ def main():
                 "frac": round(pps / ceiling, 3),
                 "note": "integer-VALU issue bound: ~26.5k instructions per permutation; a single 2^17-leaf proof only offers 2 waves/SIMD"}
 
+    # whole-proof algorithmic bytes B(n, s) against the HBM peak
+    d = sc.desc; n_, N_ = sc.n, sc.N
+    s_ = 4 if d.zero_knowledge else 0
+    W_, R_, S_ = d.num_wires, d.num_routed, d.num_constants + d.num_routed
+    Zp_, Q_ = d.num_challenges * (1 + d.num_partial_products), d.num_challenges * d.quotient_degree_factor
+    alg_bytes = (8 * W_ * n_ + 16 * (W_ + Zp_) * n_ + 16 * (W_ + Zp_ + Q_ + 3 * s_) * N_ + 192 * N_ + 8 * (2 * R_ + Zp_) * n_
+                 + 8 * (S_ + W_ + Zp_ + 2) * N_ + 16 * N_ + 64 * N_ + 8 * (S_ + W_ + Zp_ + Q_) * n_ + 8 * (S_ + W_ + Zp_ + Q_) * N_ + 16 * N_ + 37 * N_)
     nproofs = args.steps * args.batch * world
+    whole = {"alg_bytes_per_proof": alg_bytes, "achieved_GBps": round(alg_bytes * nproofs / world / dt / 1e9, 2),
+             "hbm_frac": round(alg_bytes * nproofs / world / dt / 8e12, 5), "hbm_floor_ms": round(alg_bytes / 8e12 * 1e3, 4),
+             "note": "per GPU; B(n,s) from SURVEY.md §8(d); the proof is bound by integer VALU issue (Poseidon) and dependent-stage latency, not HBM"}
     out = {
         "metric": "wormhole proofs/s", "value": round(nproofs / dt, 3), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64 (Goldilocks field, 64-bit modular integer)", "data": "synthetic",
         "config": {"workload": {"A": "single wormhole-shaped leaf proof, non-zk, degree 2^13 (BASELINE configs[1] shape of the reference tests)",
                                 "B": "single wormhole-shaped leaf proof, zk config, degree 2^14 (BASELINE configs[1])",
-                                "V": "voting-shaped proof at 2^20 rows (BASELINE configs[4])"}.get(args.preset, args.preset),
+                                "V": "voting-shaped proof at 2^20 rows (BASELINE configs[4])",
+                                "R": "recursion-shaped proof (all 14 gate types of the in-circuit verifier), non-zk, degree 2^13"}.get(args.preset, args.preset),
                    "preset": args.preset, "proofs_per_step": args.batch, "degree_bits": int(sc.desc.degree_bits),
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
-        "roofline": roofline, "valu_roofline": valu, "pipelined": pipelined, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample

@@ -23,14 +23,82 @@ static constexpr u64 GL_EPS = 0xFFFFFFFFULL;
 static constexpr u64 GL_GEN = 14293326489335486720ULL;     // multiplicative generator = LDE coset shift
 static constexpr u64 GL_POW2_GEN = 7277203076849721926ULL;  // generator of the 2^32 subgroup
 
+#if defined(__HIPCC__)
+// ---- gfx950 carry-flag primitives. From C the compiler rebuilds carries with 64-bit compares + v_cndmask and never uses the
+// carry-out of v_mad_u64_u32; spelled with the flags a modular multiply is 14 VALU instructions instead of 21-31 and an
+// add/sub 5-6 instead of 7-8. Carries live in SGPR pairs (wave masks); the asm is not volatile, so independent chains still
+// interleave. (profiles/r01_valu_issue_rates.txt: v_mad_u64_u32 and 64-bit adds issue at ~4.3 cycles, 32-bit ops at ~2.4.)
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+__device__ __forceinline__ u64 mad_co(u32 a, u32 b, u64 c, u64& co) {          // a*b + c and the carry out of bit 63
+  u64 d; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ u32 add_co(u32 a, u32 b, u64& co) { u32 d; asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(co) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 addc_co(u32 a, u32 b, u64 ci, u64& co) {        // a + b + carry_in
+  u32 d; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "s"(ci)); return d;
+}
+__device__ __forceinline__ u32 sub_co(u32 a, u32 b, u64& bo) { u32 d; asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(bo) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 subb_co(u32 a, u32 b, u64 bi, u64& bo) {        // a - b - borrow_in
+  u32 d; asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(bo) : "v"(a), "v"(b), "s"(bi)); return d;
+}
+__device__ __forceinline__ u32 sel_mask(u32 if0, u32 if1, u64 m) { u32 d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if0), "v"(if1), "s"(m)); return d; }
+__device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// (l1:l0) + 2^64*hi [- 1 if HAS_BQ and borrow mask bq is set: a pending 2^96 = -1 term]  ->  lazy residue (any u64 congruent mod p).
+// S = lo + h0*(2^32-1) - h1 - bq lies in (-2^32, 2^65 - 2^33), so floor(S/2^64) = c - b is in {-1,0,1} and
+// r_raw + (c-b)(2^32-1) cannot wrap.
+template <bool HAS_BQ>
+__device__ __forceinline__ u64 red_parts(u32 l0, u32 l1, u64 hi, u64 bq) {
+  const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+  u64 b, c;
+  const u32 x0 = HAS_BQ ? subb_co(l0, h1, bq, b) : sub_co(l0, h1, b);
+  const u32 x1 = subb_co(l1, 0u, b, b);
+  u64 r = mad_co(h0, 0xFFFFFFFFu, pack64(x0, x1), c);
+  r += sel_mask(0u, 0xFFFFFFFFu, c);
+  r -= sel_mask(0u, 0xFFFFFFFFu, b);
+  return r;
+}
+__device__ __forceinline__ u64 red128_lazy(u64 lo, u64 hi) { return red_parts<false>((u32)lo, (u32)(lo >> 32), hi, 0); }
+// a*b -> lazy residue; a, b any u64
+__device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 cq;
+  const u64 p0 = mad32(a0, b0, 0);
+  const u64 p1 = mad32(a0, b1, p0 >> 32);            // < 2^64
+  const u64 p2 = mad_co(a1, b0, p1, cq);             // 65 bits: cq:p2; cq has weight 2^96 = -1 (mod p)
+  const u64 hi = mad32(a1, b1, p2 >> 32);
+  return red_parts<true>((u32)p0, (u32)p2, hi, cq);
+}
+__device__ __forceinline__ u64 canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+#endif
+
 // Branch-free (select) forms: on the host the inputs are effectively random, so branches would mispredict.
 QP_HD u64 gl_add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // s = a + b < 2p. s - p == s + (2^32-1) mod 2^64, and that add carries exactly when s >= p; take it if either add carried.
+  u64 c1, c2;
+  const u32 s0 = add_co((u32)a, (u32)b, c1), s1 = addc_co((u32)(a >> 32), (u32)(b >> 32), c1, c1);
+  const u32 t0 = add_co(s0, 0xFFFFFFFFu, c2), t1 = addc_co(s1, 0u, c2, c2);
+  const u64 m = c1 | c2;
+  return pack64(sel_mask(s0, t0, m), sel_mask(s1, t1, m));
+#else
   u64 s = a + b;
   u64 wrapped = 0 - (u64)(s < a);                 // all ones if the 64-bit add wrapped (2^64 == 2^32 - 1 mod p)
   u64 over = 0 - (u64)(s >= GL_P);                // only meaningful when not wrapped
   return s + (wrapped & GL_EPS) - (~wrapped & over & GL_P);   // canonical for canonical inputs
+#endif
 }
-QP_HD u64 gl_sub(u64 a, u64 b) { u64 d = a - b; return d + ((0 - (u64)(a < b)) & GL_P); }
+QP_HD u64 gl_sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // d = a - b; on borrow add p, i.e. subtract 2^32 - 1
+  u64 bo, b2;
+  const u32 d0 = sub_co((u32)a, (u32)b, bo), d1 = subb_co((u32)(a >> 32), (u32)(b >> 32), bo, bo);
+  const u32 e = sel_mask(0u, 0xFFFFFFFFu, bo);
+  const u32 r0 = sub_co(d0, e, b2), r1 = subb_co(d1, 0u, b2, b2);
+  return pack64(r0, r1);
+#else
+  u64 d = a - b; return d + ((0 - (u64)(a < b)) & GL_P);
+#endif
+}
 QP_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
 QP_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
@@ -49,7 +117,13 @@ QP_HD u64 gl_reduce128(u64 lo, u64 hi) {
   t2 -= (0 - (u64)(t2 >= GL_P)) & GL_P;
   return t2;
 }
-QP_HD u64 gl_mul(u64 a, u64 b) { u64 lo, hi; mul64wide(a, b, lo, hi); return gl_reduce128(lo, hi); }
+QP_HD u64 gl_mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return canon(mul_lazy(a, b));
+#else
+  u64 lo, hi; mul64wide(a, b, lo, hi); return gl_reduce128(lo, hi);
+#endif
+}
 QP_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 QP_HD u64 gl_pow(u64 a, u64 e) { u64 r = 1; while (e) { if (e & 1) r = gl_mul(r, a); a = gl_sqr(a); e >>= 1; } return r; }
 QP_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }

@@ -12,35 +12,17 @@
 
 namespace qp {
 
-__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
-
-// lo + 2^64*hi  ->  lazy residue (any u64 congruent mod p)
-__device__ __forceinline__ u64 red128_lazy(u64 lo, u64 hi) {
-  const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
-  unsigned long long t0;
-  const bool b = __builtin_usubll_overflow((unsigned long long)lo, (unsigned long long)h1, &t0);   // wrapped by 2^64: owe -(2^32-1)
-  const u64 t2 = mad32(h0, 0xFFFFFFFFu, (u64)t0);                                                  // + h0 * (2^32-1), one v_mad_u64_u32
-  const bool c = t2 < (u64)t0;                                                                     // wrapped: owe +(2^32-1)
-  // t2 + (c - b)(2^32-1) in wrapping arithmetic; cannot wrap again
-  return t2 + ((c ? GL_EPS : 0) - (b ? GL_EPS : 0));
-}
-__device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
-  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  u64 p0 = mad32(a0, b0, 0);
-  u64 p1 = mad32(a0, b1, p0 >> 32);
-  u64 p2 = mad32(a1, b0, (u32)p1);
-  u64 hi = mad32(a1, b1, (p1 >> 32) + (p2 >> 32));
-  u64 lo = (p2 << 32) | (u32)p0;
-  return red128_lazy(lo, hi);
-}
+// mad32, mad_co, add_co/addc_co/sub_co/subb_co, sel_mask, pack64, red_parts, red128_lazy, mul_lazy, canon: gl.h (device section)
 // 128-bit product a*b -> (lo, hi)
 __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  u64 p0 = mad32(a0, b0, 0);
-  u64 p1 = mad32(a0, b1, p0 >> 32);
-  u64 p2 = mad32(a1, b0, (u32)p1);
-  hi = mad32(a1, b1, (p1 >> 32) + (p2 >> 32));
-  lo = (p2 << 32) | (u32)p0;
+  u64 cq, unused;
+  const u64 p0 = mad32(a0, b0, 0);
+  const u64 p1 = mad32(a0, b1, p0 >> 32);
+  const u64 p2 = mad_co(a1, b0, p1, cq);
+  const u64 h = mad32(a1, b1, p2 >> 32);
+  hi = pack64((u32)h, addc_co((u32)(h >> 32), 0u, cq, unused));      // the product is < 2^128: no carry out
+  lo = pack64((u32)p0, (u32)p2);
 }
 // a0*b0 + a1*b1 (two 128-bit products, one reduction); result lazy. 2^128 == -2^32 (mod p).
 __device__ __forceinline__ u64 dot2_lazy(u64 a0, u64 b0, u64 a1, u64 b1) {
@@ -54,14 +36,16 @@ __device__ __forceinline__ u64 dot2_lazy(u64 a0, u64 b0, u64 a1, u64 b1) {
   u64 d = r - sub; if (r < sub) d += GL_P;     // r + p - sub, cannot wrap twice since sub <= 2^32
   return d;
 }
-// 192-bit accumulator for sums of 128-bit products (up to 2^32 terms)
+// 192-bit accumulator for sums of 128-bit products (up to 2^32 terms): one carry chain of five 32-bit adds per product
 struct Acc192 { u64 lo, hi; u32 top; };
 __device__ __forceinline__ void acc_mul(Acc192& a, u64 x, u64 y) {
-  u64 l, h; mul_wide(x, y, l, h);
-  a.lo += l; u64 c = a.lo < l;
-  a.hi += h; u32 c2 = a.hi < h;
-  a.hi += c; c2 += (a.hi < c);
-  a.top += c2;
+  u64 l, h, c; mul_wide(x, y, l, h);
+  const u32 r0 = add_co((u32)a.lo, (u32)l, c);
+  const u32 r1 = addc_co((u32)(a.lo >> 32), (u32)(l >> 32), c, c);
+  const u32 r2 = addc_co((u32)a.hi, (u32)h, c, c);
+  const u32 r3 = addc_co((u32)(a.hi >> 32), (u32)(h >> 32), c, c);
+  a.top = addc_co(a.top, 0u, c, c);
+  a.lo = pack64(r0, r1); a.hi = pack64(r2, r3);
 }
 // canonical value of the accumulator: lo + 2^64 hi + 2^128 top, with 2^128 == -2^32
 __device__ __forceinline__ u64 acc_reduce(const Acc192& a) {
@@ -75,12 +59,19 @@ __device__ __forceinline__ u64 sbox7_lazy(u64 x) {
   u64 x2 = mul_lazy(x, x), x4 = mul_lazy(x2, x2), x3 = mul_lazy(x2, x);
   return mul_lazy(x3, x4);
 }
-__device__ __forceinline__ u64 canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
 // x + c for lazy x and canonical c
 __device__ __forceinline__ u64 add_lazy_canon(u64 x, u64 c) {
   u64 s = x + c; if (s < c) s += GL_EPS; return s;
 }
 
+// sl + 2^32*sh for column sums sl, sh < 2^44  ->  lazy residue: 2^32*sh = (sh_lo << 32) + sh_hi*(2^32-1); t < 2^45, so after a carry
+// out of the high-word add the wrapped value is < 2^45 and the +(2^32-1) correction cannot wrap again.
+__device__ __forceinline__ u64 mds_row_fold(u64 sl, u64 sh) {
+  const u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
+  u64 k;
+  const u32 vh = add_co((u32)(t >> 32), (u32)sh, k);
+  return pack64((u32)t, vh) + sel_mask(0u, 0xFFFFFFFFu, k);
+}
 // MDS with the next round's constants folded in: st[r] = sum_i C[i]*st[(i+r)%12] + 8*st[0]*[r==0] + rc[r]   (lazy)
 __device__ __forceinline__ void mds_rc_lazy(u64 st[12], const u64* __restrict__ rc) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -95,11 +86,7 @@ __device__ __forceinline__ void mds_rc_lazy(u64 st[12], const u64* __restrict__ 
     for (int i = 0; i < 12; i++) { sl = mad32(lo[(i + r) % 12], C[i], sl); sh = mad32(hi[(i + r) % 12], C[i], sh); }
     if (r == 0) { sl = mad32(lo[0], 8, sl); sh = mad32(hi[0], 8, sh); }
     // value = sl + 2^32*sh, sl, sh < 2^43:  2^32*sh = (sh_lo << 32) + sh_hi*2^64 == (sh_lo << 32) + sh_hi*(2^32-1)
-    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
-    u64 add = (u64)(u32)sh << 32;
-    u64 v = t + add;
-    if (v < add) v += GL_EPS;
-    st[r] = v;
+    st[r] = mds_row_fold(sl, sh);
   }
 }
 
@@ -162,11 +149,7 @@ __device__ __forceinline__ void pair_mds_rc(u64 own[6], const PairCtx& cx, const
       sl = mad32(olo[jj], cx.co[d], sl); sh = mad32(ohi[jj], cx.co[d], sh);
     }
     if (j == 0) { sl = mad32(lo[0], cx.d0, sl); sh = mad32(hi[0], cx.d0, sh); }
-    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
-    u64 add = (u64)(u32)sh << 32;
-    u64 v = t + add;
-    if (v < add) v += GL_EPS;
-    own[j] = v;
+    own[j] = mds_row_fold(sl, sh);
   }
 }
 // Both lanes of a pair must call this together (whole waves: never under divergent control flow). Output canonical.
@@ -235,10 +218,7 @@ __device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64
     u64 sl = (u32)cc, sh = cc >> 32;
 #pragma unroll
     for (int j = 0; j < 12; j++) { u64 v = buf[j]; sl = mad32((u32)v, cx.m[j], sl); sh = mad32((u32)(v >> 32), cx.m[j], sh); }
-    u64 t = mad32((u32)(sh >> 32), 0xFFFFFFFFu, sl);
-    u64 add = (u64)(u32)sh << 32;
-    x = t + add;
-    if (x < add) x += GL_EPS;
+    x = mds_row_fold(sl, sh);
   }
   __syncthreads();
   return canon(x);
