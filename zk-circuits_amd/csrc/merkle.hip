@@ -17,6 +17,7 @@ void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s) {
 }
 
 __global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
   __threadfence_system();
   __syncthreads();
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor_pair(const u64* cols, s
   }
 }
 __global__ void __launch_bounds__(256) k_level_pair(const u64* in, u64* out, size_t parents) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const int p = (int)(gid & 1);
   size_t node = gid >> 1; const bool live = node < parents; if (!live) node = parents - 1;
@@ -198,6 +200,7 @@ __global__ void __launch_bounds__(256) k_leaves_fri(const u64* a, const u64* b, 
 }
 // cooperative form: 16 lanes per leaf (layers have few leaves, each a short sponge)
 __global__ void __launch_bounds__(64) k_leaves_fri_coop(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   __shared__ u64 xch[4][24];
   const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
   const size_t L = (size_t)blockIdx.x * 4 + g, LL = L < num_leaves ? L : num_leaves - 1;
@@ -234,6 +237,7 @@ __global__ void __launch_bounds__(256) k_level_lane(const u64* in, u64* out, siz
   for (int k = 0; k < 4; k++) out[p * 4 + k] = st[k];
 }
 __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size_t parents) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   __shared__ u64 xch[4][24];
   const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
   const size_t p = (size_t)blockIdx.x * 4 + g;
@@ -242,6 +246,36 @@ __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size
   u64 x = i < 8 ? in[pp * 8 + i] : 0;
   x = coop_permute(x, i, cx, xch[g]);
   if (p < parents && i < 4) out[p * 4 + i] = x;
+}
+// Several consecutive latency-bound levels in one launch: a block of G 16-lane groups takes 2G sibling digests and climbs
+// log2(G)+1 levels, halving its active groups each time; every level is also written to the tree (query paths need all levels).
+// A ~12 us level costs ~4 us of dispatch/drain as its own kernel, so the 11 small levels of a 2^17-leaf tree go from 11 launches
+// to 2. The permutation's lane exchange is wave-local (COOP_SYNC), so only the level hand-off needs workgroup barriers, and waves
+// whose groups have all retired skip the permutation.
+static int getenv_int_m(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
+template <int G>
+__global__ void __launch_bounds__(16 * G) k_levels_coop_fused(const u64* __restrict__ in, u64* __restrict__ out, size_t parents0, int nlev) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ u64 xch[G][24];
+  __shared__ u64 dig[G][4];
+  const int g = threadIdx.x >> 4, i = threadIdx.x & 15, wave_g0 = g & ~3;
+  CoopCtx cx; coop_init(cx, i);
+  size_t par = parents0;
+  const size_t p0 = (size_t)blockIdx.x * G + g;
+  u64 x = (i < 8 && p0 < par) ? in[p0 * 8 + i] : 0;
+  u64* o = out;
+  for (int k = 0; k < nlev; k++) {
+    const int act = G >> k;                                    // groups of this block still holding a parent
+    if (wave_g0 < act) x = coop_permute(x, i, cx, xch[g]);
+    const size_t q = (size_t)blockIdx.x * act + g;
+    if (g < act && q < par && i < 4) { o[q * 4 + i] = x; dig[g][i] = x; }
+    __syncthreads();
+    u64 nx = 0;
+    if (k + 1 < nlev && g < (act >> 1) && i < 8) nx = dig[2 * g + (i >> 2)][i & 3];
+    __syncthreads();
+    x = nx;
+    o += par * 4; par >>= 1;
+  }
 }
 static constexpr size_t COOP_MAX_PARENTS = 16384;
 void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done, bool shared_gpu) {
@@ -256,7 +290,17 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
     size_t parents = cnt >> 1; u64* out = cur + cnt * 4;
     if (parents > (pair_max > coop_max ? pair_max : coop_max)) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
     else if (parents > coop_max) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
-    else hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, cur, out, parents);
+    else {
+      // latency-bound tail: climb up to 6 levels per launch
+      static const int fuse = getenv_int_m("QPGPU_FUSE_LEVELS", 1);
+      int nlev = 0; { size_t c2 = cnt; while (c2 > cap && nlev < 6) { c2 >>= 1; nlev++; } }
+      if (fuse && nlev >= 2 && parents >= 32) {
+        hipLaunchKernelGGL(k_levels_coop_fused<32>, dim3((unsigned)((parents + 31) / 32)), dim3(512), 0, s, cur, out, parents, nlev);
+        for (int k = 0; k < nlev; k++) { cur += cnt * 4; cnt >>= 1; }
+        continue;
+      }
+      hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, cur, out, parents);
+    }
     cur = out; cnt = parents;
   }
 }

@@ -735,13 +735,13 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
   if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
   if (out_stride < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "out_stride smaller than proof size");
   if (batch == 0) return 0;
-  int workers = getenv_int("QPGPU_STREAMS", 4); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
+  int workers = getenv_int("QPGPU_STREAMS", 2); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
   std::atomic<size_t> next(0); std::atomic<int> first_rc(0); std::mutex emu; std::string emsg;
   auto body = [&]() {
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
-    w->shared_gpu = workers > 1;
+    w->shared_gpu = getenv_int("QPGPU_SHARED_MODE", 0) != 0;   // the batch-mode kernel choices stopped paying once the field arithmetic got cheaper (profiles/r01_notes_ab_experiments.md)
     for (;;) {
       size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
       qpgpu_prove_opts o; if (opts) o = *opts; else memset(&o, 0, sizeof o);
