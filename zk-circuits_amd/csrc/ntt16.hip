@@ -22,6 +22,16 @@ __device__ __forceinline__ u64 root_pow16(const u64* rt, int log_M, u64 e) {
   u64 M = 1ULL << log_M; e &= (M - 1); u64 half = M >> 1;
   return e < half ? rt[e] : gl_neg(rt[e - half]);
 }
+// Same value through two small windows of the table: w^e = w^(e_hi * 2^12) * w^(e_lo). A strided pass's output twiddles
+// w^(low * F) walk the whole table (one distinct 64-byte line per element: at log_M = 23 a 64 MB footprint that lives in neither
+// L2 nor comfortably in MALL); the two windows are 32 KB contiguous + (M/2^13) lines, so they stay in L2. One extra multiply.
+__device__ __forceinline__ u64 root_pow2w(const u64* rt, int log_M, u64 e) {
+  if (log_M <= 17) return root_pow16(rt, log_M, e);                 // the whole table (<= 512 KB) is L2-resident anyway
+  const u64 M = 1ULL << log_M; e &= (M - 1); const u64 half = M >> 1;
+  const bool neg = e >= half; e &= half - 1;
+  const u64 v = gl_mul(rt[(e >> 12) << 12], rt[e & 4095]);
+  return neg ? gl_neg(v) : v;
+}
 __device__ __forceinline__ unsigned lpos(unsigned e) { return e + (e >> 4); }
 
 // 16-point DIF, output in bit-reversed register order: x[r] = sum_k in[k] W^(k * rev4(r))
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(256) k_ntt_strided_reg(StridedArgs a) {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     u64 v = x[r];
-    if (r) { u64 e = unit * rev_m(r, M); if (a.inverse) e = Mfull - e; v = mulc(v, root_pow16(a.rt, a.log_M, e)); }
+    if (r) { u64 e = unit * rev_m(r, M); if (a.inverse) e = Mfull - e; v = mulc(v, root_pow2w(a.rt, a.log_M, e)); }
     dst[base + ((size_t)r << a.b_lo)] = v;
   }
 }
@@ -235,7 +245,7 @@ __global__ void __launch_bounds__(256) k_ntt_strided8(StridedArgs a) {
   for (int r = 0; r < 16; r++) {
     const unsigned hpp = B * 16 + r, F = rev_m(hpp, 8);
     u64 v = x[r];
-    if (F) { u64 e = unit * F; if (a.inverse) e = Mfull - e; v = mulc(v, root_pow16(a.rt, a.log_M, e)); }
+    if (F) { u64 e = unit * F; if (a.inverse) e = Mfull - e; v = mulc(v, root_pow2w(a.rt, a.log_M, e)); }
     dst[base + ((size_t)hpp << a.b_lo)] = v;
   }
 }
@@ -264,8 +274,9 @@ void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_strid
   const size_t n = size_t(1) << log_n; const unsigned transforms = (unsigned)(count << log_cosets);
   int rem = log_n; bool first = true;
   while (rem > 12) {
+    static const int use_m8 = [] { const char* v = getenv("QPGPU_NTT_M8"); return v ? atoi(v) : 1; }();
     int M = rem - 12 <= 4 ? rem - 12 : (rem - 9 < 8 ? rem - 9 : 8);
-    if (M > 4 && M < 8) M = 4;                       // only M <= 4 (registers) and M = 8 (one LDS exchange) exist
+    if (M > 4 && (M < 8 || !use_m8)) M = 4;          // only M <= 4 (registers) and M = 8 (one LDS exchange) exist
     a.b_lo = rem - M; a.first = first ? 1 : 0;
     if (M == 8) hipLaunchKernelGGL(k_ntt_strided8, dim3((unsigned)(n >> 12), transforms), dim3(256), 0, s, a);
     else {
