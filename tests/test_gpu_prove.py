@@ -164,9 +164,11 @@ def test_varied_circuit_shapes_match_oracle(shape):
         gc.close()
 
 
-def test_split_quotient_path_matches_oracle(monkeypatch):
-    """The opt-in split quotient (gate terms / permutation terms on a side stream + alpha combine) gives the same bytes."""
-    monkeypatch.setenv("QPGPU_SPLIT_QUOTIENT", "1")
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_split_quotient_path_matches_oracle(monkeypatch, mode):
+    """The split quotient (gate terms / permutation terms on a side stream + alpha combine; default for single proofs) and the
+    fused kernel (QPGPU_SPLIT_QUOTIENT=0; always used by stream-pipelined batches) give the same bytes."""
+    monkeypatch.setenv("QPGPU_SPLIT_QUOTIENT", mode)
     for preset in ("T", "TZ"):
         sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)     # env is read at circuit creation
         try:

@@ -64,7 +64,8 @@ struct Workspace {
   u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
   u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
   u64 pub_seq = 0;
-  bool shared_gpu = false;    // set for workers of qpgpu_prove_batch: several proofs share the chip
+  bool shared_gpu = false;    // opt-in (QPGPU_SHARED_MODE=1): kernel choices that assume other proofs fill the chip
+  bool batch_mode = false;    // set for workers of qpgpu_prove_batch when several proofs share the chip: fused quotient kernel
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
   u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
@@ -524,7 +525,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
-  const bool split = c->split_quotient;
+  const bool split = c->split_quotient && !w->batch_mode;
   commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s, [&] {
     if (!split || getenv_int("QPGPU_SPLIT_SERIAL", 0)) return;   // gate-constraint terms: only wires + constants, run beside the wires leaf hash
     (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
@@ -741,6 +742,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
+    w->batch_mode = workers > 1;
     w->shared_gpu = getenv_int("QPGPU_SHARED_MODE", 0) != 0;   // the batch-mode kernel choices stopped paying once the field arithmetic got cheaper (profiles/r01_notes_ab_experiments.md)
     for (;;) {
       size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
@@ -751,7 +753,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
       if (rc) { (void)hipStreamSynchronize(w->stream); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
       if (out_lens) out_lens[i] = c->lay.total;
     }
-    w->shared_gpu = false;
+    w->shared_gpu = false; w->batch_mode = false;
     ws_release(c, w);
   };
   std::vector<std::thread> th;

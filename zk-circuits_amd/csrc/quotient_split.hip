@@ -171,11 +171,14 @@ static Zh8q make_zh(const CircuitDev& cd) {
 }
 
 bool quotient_split_supported(const CircuitDev& cd) {
-  // Opt-in (QPGPU_SPLIT_QUOTIENT=1, read when a circuit is created). Measured on MI355X, config B: single proof 4.80 vs 4.87 ms
-  // (+1.5 %), stream-pipelined 237 vs 285 proofs/s (-17 %: +300 MB of traffic and two more kernels per proof when the chip is
-  // already saturated) — so the fused kernel stays the default.
+  // Default for single proofs of the leaf gate set up to 2^20 LDE points (QPGPU_SPLIT_QUOTIENT=0 disables; read when a circuit is
+  // created). The gate-constraint terms need only wires + constants, so they run beside the wires leaf hash (which alone offers
+  // 2 waves/SIMD), the permutation terms beside the Z leaf hash, and only the alpha combination stays on the critical path.
+  // MI355X, config B: single proof 3.89 vs 4.00 ms. Stream-pipelined batches keep the fused kernel (336 vs 341 proofs/s: the extra
+  // ~300 MB of traffic buys nothing when other proofs already fill the chip) — qpgpu_prove_batch switches it off per call.
   const char* v = getenv("QPGPU_SPLIT_QUOTIENT");
-  if (!(v && v[0] == '1')) return false;
+  if (v && v[0] == '0') return false;
+  if (cd.log_n + cd.rate_bits > 20 && !(v && v[0] == '1')) return false;     // 145 extra columns of N per workspace
   int seen[16] = {0}; bool poseidon = false;
   for (int i = 0; i < cd.num_gates; i++) {
     u32 t = cd.gates[i].tag; if (t >= 16 || seen[t]++) return false;
