@@ -120,3 +120,21 @@ def test_parse_reference_common_and_verifier_bins():
     L.qpgpu_parse_verifier_only.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
     assert L.qpgpu_parse_verifier_only(vb, 552, cap, 64, dig) == 4
     assert [hex(x) for x in dig] == ["0x8713e1b2b4082ea4", "0x188a85b2cad283d6", "0xd750e61c805b7185", "0xdd6c289a955012e3"]   # SURVEY App. A.6 digest pin
+
+
+def test_host_transcript_permutation_fast_form_equals_literal_form():
+    """The host Challenger's permutation uses derived 'fast partial round' tables (tools/gen_poseidon_fast.py); it must equal
+    the literal round-by-round permutation on random and edge-case states, and the two known-answer vectors of SURVEY App. A.2."""
+    import random
+    S = synth(); S.qpsynth_host_permute.argtypes = [u64p, ctypes.c_int]
+    rnd = random.Random(11)
+    edge = [0, 1, P - 1, P - 2, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 63]
+    for it in range(3000):
+        st = np.array([rnd.choice(edge) if it % 5 == 0 else rnd.randrange(P) for _ in range(12)], dtype=np.uint64)
+        a, b = st.copy(), st.copy()
+        S.qpsynth_host_permute(ptr(a), 0); S.qpsynth_host_permute(ptr(b), 1)
+        assert np.array_equal(a, b)
+    z = np.zeros(12, dtype=np.uint64); S.qpsynth_host_permute(ptr(z), 0)
+    assert [int(x) for x in z[:4]] == [0x3c18a9786cb0b359, 0xc4055e3364a246c3, 0x7953db0ab48808f4, 0xc71603f33a1144ca]
+    s = np.arange(12, dtype=np.uint64); S.qpsynth_host_permute(ptr(s), 0)
+    assert [int(x) for x in s[:4]] == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47, 0xd40285597c6a8825, 0x613a4f81e81231d2]

@@ -5,6 +5,7 @@
 #pragma once
 #include "gl.h"
 #include "poseidon_constants.h"
+#include "poseidon_fast_constants.h"
 
 namespace qp {
 
@@ -137,13 +138,49 @@ static inline void mds_rc(u64 st[12], const u64* rc) {
   QP_UNROLL_ALL for (int r = 0; r < 12; r++) st[r] = out[r];
 }
 }
+// ---- fast form of the 22 partial rounds (tools/gen_poseidon_fast.py derives and checks the tables): each round is one S-box,
+// one 11-term dot product and 11 multiply-adds instead of a full 12x12 MDS product. Only the host uses it: on the GPU the
+// small-constant MDS needs no per-term reductions and is cheaper than 22 full multiplications.
+namespace hostp {
+static const u64 FAST_FIRST[12] = {QP_POSEIDON_FAST_FIRST};
+static const u64 FAST_Q[22] = {QP_POSEIDON_FAST_Q};
+static const u64 FAST_INIT[11][11] = {QP_POSEIDON_FAST_INIT};
+static const u64 FAST_WHAT[22][11] = {QP_POSEIDON_FAST_WHAT};
+static const u64 FAST_V[22][11] = {QP_POSEIDON_FAST_V};
+typedef unsigned __int128 u128;
+// sum_j a[j]*x[j] (+ c0*x0) for 11 terms of full 64-bit factors: low and high product halves accumulate separately (no overflow for
+// < 2^64 terms), then lo + 2^64*mid + 2^128*top with 2^128 == -2^32 (mod p). Result lazy.
+static inline u64 dot11(const u64* a, const u64* x, u64 c0, u64 x0) {
+  u128 p = (u128)c0 * x0;
+  u128 alo = (u64)p, ahi = (u64)(p >> 64);
+  QP_UNROLL_ALL for (int j = 0; j < 11; j++) { p = (u128)a[j] * x[j]; alo += (u64)p; ahi += (u64)(p >> 64); }
+  const u128 mid = (alo >> 64) + (u64)ahi;
+  const u64 top = (u64)(ahi >> 64) + (u64)(mid >> 64);            // < 32
+  u64 r = red128((u64)alo, (u64)mid);
+  const u64 sub = top << 32;
+  u64 d = r - sub; if (__builtin_expect(r < sub, 0)) d += GL_P;
+  return d;
+}
+}
 inline void poseidon_permute(u64 st[12]) {
   const u64* rc = POSEIDON_RC_HOST;
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::addc(st[i], rc[i]);
   int r = 0;
-  for (; r < 4; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
-  for (; r < 26; r++) { st[0] = hostp::sbox(st[0]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
-  for (; r < 29; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
+  for (; r < 4; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, r < 3 ? rc + 12 * (r + 1) : hostp::FAST_FIRST); }
+  { u64 t[11];
+    for (int i = 0; i < 11; i++) t[i] = hostp::dot11(hostp::FAST_INIT[i], st + 1, 0, 0);
+    for (int i = 0; i < 11; i++) st[1 + i] = t[i]; }
+  for (int t = 0; t < 22; t++) {
+    const u64 s0 = hostp::addc(hostp::sbox(st[0]), hostp::FAST_Q[t]);
+    const u64 d = hostp::dot11(hostp::FAST_WHAT[t], st + 1, 25, s0);
+    QP_UNROLL_ALL for (int j = 0; j < 11; j++) {
+      const hostp::u128 p = (hostp::u128)s0 * hostp::FAST_V[t][j] + st[1 + j];
+      st[1 + j] = hostp::red128((u64)p, (u64)(p >> 64));
+    }
+    st[0] = d;
+  }
+  QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::addc(st[i], rc[12 * 26 + i]);
+  for (r = 26; r < 29; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]);
   hostp::mds_rc(st, nullptr);
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] -= (0 - (u64)(st[i] >= GL_P)) & GL_P;

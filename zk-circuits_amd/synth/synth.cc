@@ -65,6 +65,8 @@ struct qpsynth_circuit {
 extern "C" {
 
 const char* qpsynth_last_error(void) { return g_err.c_str(); }
+// test hook: the host transcript permutation (fast form) or the literal round-by-round one, on a 12-word state
+void qpsynth_host_permute(uint64_t* st, int generic) { if (generic) poseidon_permute_generic(st); else poseidon_permute(st); }
 
 int qpsynth_preset(const char* name, qpsynth_params* o) {
   memset(o, 0, sizeof *o);
