@@ -283,7 +283,7 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
   // permutation. Stream-pipelined throughput did not improve — 257-278 vs 285 proofs/s — the longer per-proof critical path
   // costs more overlap than the saved instructions buy, so both modes use the same thresholds.)
   (void)shared_gpu;
-  const size_t pair_max = PAIR_MAX_LEAVES, coop_max = COOP_MAX_PARENTS;
+  static const size_t pair_max = (size_t)getenv_int_m("QPGPU_PAIR_MAX", (int)PAIR_MAX_LEAVES), coop_max = (size_t)getenv_int_m("QPGPU_COOP_MAX", (int)COOP_MAX_PARENTS);   // env: tuning experiments
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
   for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {
