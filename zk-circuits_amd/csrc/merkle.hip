@@ -68,16 +68,35 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
   if (width <= 4) {
     for (int k = 0; k < width; k++) st[k] = cols[(size_t)k * col_stride + L];
   } else {
-    for (int off = 0; off < width; off += 8) {
-      int m = width - off < 8 ? width - off : 8;
-      if (m == 8) {
+    if constexpr (!FUSE) {
+      // software-pipelined absorb: the next chunk's eight column loads are in flight while the current chunk is permuted (the loop
+      // otherwise exposes one HBM round trip per chunk: 18 for the wires oracle). Only for trees that do not fill the chip: with
+      // many blocks per SIMD queued (the FUSE variant, >= 2^20 leaves) other waves already hide the loads and the 24 extra
+      // VGPRs cost an occupancy step (measured 31.3 vs 30.0 ms per launch at 2^23 leaves).
+      u64 nxt[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) st[k] = cols[(size_t)(off + k) * col_stride + L];
-      } else {
+      for (int k = 0; k < 8; k++) nxt[k] = k < width ? cols[(size_t)k * col_stride + L] : 0;
+      for (int off = 0; off < width; off += 8) {
+        const int m = width - off < 8 ? width - off : 8;
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (k < m) st[k] = cols[(size_t)(off + k) * col_stride + L];
+        for (int k = 0; k < 8; k++) if (k < m) st[k] = nxt[k];
+        const int off2 = off + 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (off2 + k < width) nxt[k] = cols[(size_t)(off2 + k) * col_stride + L];
+        poseidon_permute_dev(st);
       }
-      poseidon_permute_dev(st);
+    } else {
+      for (int off = 0; off < width; off += 8) {
+        const int m = width - off < 8 ? width - off : 8;
+        if (m == 8) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) st[k] = cols[(size_t)(off + k) * col_stride + L];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (k < m) st[k] = cols[(size_t)(off + k) * col_stride + L];
+        }
+        poseidon_permute_dev(st);
+      }
     }
   }
 #pragma unroll

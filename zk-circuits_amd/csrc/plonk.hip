@@ -196,8 +196,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int c = 0; c < nch; c++) { prev[c] = zl[(size_t)c * N + L]; bx[c] = gl_mul(betas.v[c], x); }
     for (int k = 0; k <= npp; k++) {
       u64 nu[2] = {1, 1}, de[2] = {1, 1};
-      for (int jj = k * deg; jj < (k + 1) * deg && jj < R; jj++) {
-        const u64 w = Wv(jj), sg = cs[(size_t)(NC + jj) * N + L], kj = cd.k_is[jj];
+      // a chunk's loads are issued together (deg <= 8): with 2 waves/SIMD the kernel depends on memory-level parallelism
+      u64 wv[8], sgv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int jj = k * deg + u; const bool ok = u < deg && jj < R; wv[u] = ok ? Wv(jj) : 0; sgv[u] = ok ? cs[(size_t)(NC + jj) * N + L] : 0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int jj = k * deg + u;
+        if (!(u < deg && jj < R)) continue;
+        const u64 w = wv[u], sg = sgv[u], kj = cd.k_is[jj];
         for (int c = 0; c < nch; c++) {
           nu[c] = mul_lazy(nu[c], add_lazy_canon(add_lazy_canon(mul_lazy(bx[c], kj), w), gammas.v[c]));
           de[c] = mul_lazy(de[c], add_lazy_canon(add_lazy_canon(mul_lazy(betas.v[c], sg), w), gammas.v[c]));
@@ -237,18 +244,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
       case QPGPU_GATE_BASESUM2: {
         const int limbs = (int)g.param;
         u64 sum = 0;
-        for (int l = limbs - 1; l >= 0; l--) {
-          u64 b = Wv(1 + l);
-          sum = gl_add(gl_add(sum, sum), b);
-          ACC_TERM(gl_mul(b, gl_sub(b, 1)), 1 + l);
+        for (int hi = limbs; hi > 0; hi -= 8) {                // limbs [hi-8, hi), highest first, loads issued together
+          u64 bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int l = hi - 1 - u; bv[u] = l >= 0 ? Wv(1 + l) : 0; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int l = hi - 1 - u;
+            if (l < 0) continue;
+            const u64 b = bv[u];
+            sum = gl_add(gl_add(sum, sum), b);
+            ACC_TERM(gl_mul(b, gl_sub(b, 1)), 1 + l);
+          }
         }
         ACC_TERM(gl_sub(sum, Wv(0)), 0);
         break;
       }
       case QPGPU_GATE_ARITHMETIC:
-        for (u32 i = 0; i < (u32)g.param; i++) {
-          u64 m0 = Wv(4 * i), m1 = Wv(4 * i + 1), ad = Wv(4 * i + 2), o = Wv(4 * i + 3);
-          ACC_TERM(gl_sub(o, gl_add(gl_mul(lc0, gl_mul(m0, m1)), gl_mul(lc1, ad))), i);
+        for (u32 i0 = 0; i0 < (u32)g.param; i0 += 4) {         // four operations (16 loads) per batch
+          u64 av[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) av[u] = (i0 + (u >> 2)) < (u32)g.param ? Wv(4 * i0 + u) : 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (i0 + u >= (u32)g.param) continue;
+            ACC_TERM(gl_sub(av[4 * u + 3], gl_add(gl_mul(lc0, gl_mul(av[4 * u], av[4 * u + 1])), gl_mul(lc1, av[4 * u + 2]))), i0 + u);
+          }
         }
         break;
       case QPGPU_GATE_POSEIDON: {
@@ -279,10 +300,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
           for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
           mds_rc_lazy(st, rc + 12 * (round + 1));
         }
-        for (int r = 0; r < 22; r++, round++) {
-          u64 in = Wv(65 + r); ACC_TERM(sub_lazy_canon(st[0], in), k); k++;
-          st[0] = sbox7_lazy(in);
-          mds_rc_lazy(st, rc + 12 * (round + 1));
+        for (int r0 = 0; r0 < 22; r0 += 11) {                  // the partial rounds' S-box input wires, eleven loads at a time
+          u64 pin[11];
+#pragma unroll
+          for (int u = 0; u < 11; u++) pin[u] = Wv(65 + r0 + u);
+          for (int u = 0; u < 11; u++, round++) {
+            u64 in = pin[0];
+#pragma unroll
+            for (int q = 0; q < 10; q++) pin[q] = pin[q + 1];   // shift register: keeps the array in VGPRs under the rolled loop
+            ACC_TERM(sub_lazy_canon(st[0], in), k); k++;
+            st[0] = sbox7_lazy(in);
+            mds_rc_lazy(st, rc + 12 * (round + 1));
+          }
         }
         for (int r = 0; r < 4; r++, round++) {
 #pragma unroll

@@ -154,9 +154,20 @@ __global__ void __launch_bounds__(256) k_quotient_combine(CircuitDev cd, const u
   const u32 j = rev_bits((u32)L, log_N);
   const u64* ap0 = apw; const u64* ap1 = apw + ap_stride;
   Acc192 a0{0, 0, 0}, a1{0, 0, 0};
-  for (int t = 0; t < n_perm; t++) { u64 v = Pm[(size_t)t * N + L]; acc_mul(a0, v, ap0[t]); acc_mul(a1, v, ap1[t]); }
-  ap0 += n_perm; ap1 += n_perm;
-  for (int t = 0; t < n_gate; t++) { u64 v = G[(size_t)t * N + L]; acc_mul(a0, v, ap0[t]); acc_mul(a1, v, ap1[t]); }
+  // loads batched eight at a time: at 2 waves/SIMD the kernel lives on memory-level parallelism
+  auto run = [&](const u64* __restrict__ T, int n, const u64* __restrict__ p0, const u64* __restrict__ p1) {
+    int t = 0;
+    for (; t + 8 <= n; t += 8) {
+      u64 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = T[(size_t)(t + k) * N + L];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { acc_mul(a0, v[k], p0[t + k]); acc_mul(a1, v[k], p1[t + k]); }
+    }
+    for (; t < n; t++) { const u64 v = T[(size_t)t * N + L]; acc_mul(a0, v, p0[t]); acc_mul(a1, v, p1[t]); }
+  };
+  run(Pm, n_perm, ap0, ap1);
+  run(G, n_gate, ap0 + n_perm, ap1 + n_perm);
   const u64 zi = zh.zh_inv[j & ((1u << cd.rate_bits) - 1)];
   out[L] = gl_mul(acc_reduce(a0), zi);
   if (cd.num_challenges > 1) out[N + L] = gl_mul(acc_reduce(a1), zi);
