@@ -184,10 +184,10 @@ def main():
         perms = sum(-(-w // 8) for w in widths) * sc.N
         tot_ms = kernels["merkle_leaves_colmajor"]["total_ms"] / (kernels["merkle_leaves_colmajor"]["launches"] / 3.0)
         pps = perms / (tot_ms * 1e-3)
-        ceiling = 1.90e9        # measured saturation of the one-permutation-per-lane kernel (profiles/r01_permute_occupancy_sweep.txt)
+        ceiling = 2.31e9        # measured saturation of the one-permutation-per-lane kernel (profiles/r01_permute_occupancy_sweep.txt)
         valu = {"permutations_per_s": round(pps / 1e9, 3), "unit": "G perm/s", "saturated_G_perm_per_s": round(ceiling / 1e9, 3),
                 "frac": round(pps / ceiling, 3),
-                "note": "integer-VALU issue bound: ~26.5k instructions per permutation; a single 2^17-leaf proof only offers 2 waves/SIMD"}
+                "note": "integer-VALU issue bound: ~16.7k VALU instructions (68k SIMD cycles) per permutation; a single 2^17-leaf proof only offers 2 waves/SIMD"}
 
     # whole-proof algorithmic bytes B(n, s) against the HBM peak
     d = sc.desc; n_, N_ = sc.n, sc.N

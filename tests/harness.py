@@ -273,7 +273,7 @@ class GpuCircuit:
         buf = ctypes.create_string_buffer(self.proof_size)
         n = ctypes.c_size_t()
         gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
-        return buf.raw[:n.value]
+        return ctypes.string_at(buf, n.value)          # one copy (buf.raw[:n] makes two)
 
     def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False):
         L = qpgpu()
@@ -290,7 +290,7 @@ class GpuCircuit:
         buf = ctypes.create_string_buffer(self.proof_size * b)
         lens = (ctypes.c_size_t * b)()
         gpu_check(L.qpgpu_prove_batch(self.h, b, wp, pp, len(pis_list[0]), ctypes.byref(o), buf, self.proof_size, lens))
-        return [buf.raw[i * self.proof_size:(i + 1) * self.proof_size] for i in range(b)]
+        return [ctypes.string_at(ctypes.addressof(buf) + i * self.proof_size, self.proof_size) for i in range(b)]
 
     def stage_ms(self):
         out = (ctypes.c_double * 16)()

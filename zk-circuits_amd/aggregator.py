@@ -1,10 +1,12 @@
 """WormholeProofAggregator mirror (reference: /root/reference/wormhole/aggregator/src/aggregator.rs:13-92,
 circuits/tree.rs:24-103, util.rs:11-29).
 
-Scope this round: the buffer semantics and error behaviour of push_proof / aggregate, the
-sharding of independent leaf proofs (one per GPU stream / per rank) and the RCCL gather of the fixed-size proof blobs
-that precedes the aggregator step. The recursive-verifier circuit itself needs gates outside the leaf set
-("next" rank 1), so `aggregate()` returns the gathered, padded leaf set rather than a root proof.
+Scope: the buffer semantics and error behaviour of push_proof / aggregate, the sharding of
+independent leaf proofs (one per GPU stream / per rank) and the RCCL gather of the fixed-size proof blobs that precedes the
+aggregator step. The device path proves recursion circuits too (all gates of the in-circuit verifier are evaluated by the
+quotient kernel), but the recursive-verifier circuit and its witness are built by qp-plonky2's Rust
+CircuitBuilder / generators on the host (tree.rs:106-135), which this image cannot run; so `aggregate()` here returns the
+gathered, padded leaf set — exactly what `aggregate_level` (tree.rs:92-103) consumes — rather than a root proof.
 """
 import ctypes
 import numpy as np
@@ -64,7 +66,7 @@ class WormholeProofAggregator:
         ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf,
                                               cd.proof_size, lens))
         for i in range(b):
-            self.push_proof(ProofWithPublicInputs(buf.raw[i * cd.proof_size:(i + 1) * cd.proof_size], cd.num_public_inputs))
+            self.push_proof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs))
 
     def aggregate(self, dummy_proof=None):
         if self.proofs_buffer is None:

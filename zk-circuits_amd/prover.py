@@ -149,4 +149,4 @@ class WormholeProver:
                                    buf, cd.proof_size, ctypes.byref(n))
         if rc != 0:
             raise RuntimeError("Failed to prove: %s" % ffi.lib().qpgpu_last_error().decode())
-        return ProofWithPublicInputs(buf.raw[:n.value], cd.num_public_inputs)
+        return ProofWithPublicInputs(ctypes.string_at(buf, n.value), cd.num_public_inputs)
