@@ -174,7 +174,7 @@ def main():
         if dist is not None:
             t = torch.tensor([pdt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); pdt = float(t.item())
         pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
-                     "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "2")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
+                     "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
 
     # Poseidon throughput of the dominant kernel against the measured VALU issue ceiling
     valu = None

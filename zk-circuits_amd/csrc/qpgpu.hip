@@ -209,10 +209,9 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
 
 // Commit to `cols` coefficient columns already sitting in `coeffs` ([cols][n]): LDE -> salt -> leaves -> levels; the cap is
 // is fetched by the caller (cap_ptr + fetch_to_host).
-// `fork` (optional) is invoked once the LDE (+ salt) is enqueued, before the leaf hash: work forked there onto the side stream
-// runs beside the leaf-hash kernel, which at N = 2^17 only offers 2 waves/SIMD and leaves ~15 % of the issue slots unused
-// (profiles/r01_permute_occupancy_sweep.txt). Forking AFTER the leaf hash instead — beside the latency-bound upper levels — was
-// measured to slow every level launch by ~1.3x and lose what the overlap gained.
+// `fork` (optional) forks work onto the side stream: by default after the leaf hash, beside the latency-bound tree levels
+// (which run at raised wave priority); QPGPU_SPLIT_FORK_LATE=0 forks it before the leaf hash instead (the leaf kernel at
+// N = 2^17 only offers 2 waves/SIMD and leaves issue slots unused, but sharing slows it by more than the overlap gains).
 template <class F>
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
                           u64 salt_seed, const u64* salts_host, hipStream_t s, F fork) {
@@ -740,7 +739,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
   if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
   if (out_stride < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "out_stride smaller than proof size");
   if (batch == 0) return 0;
-  int workers = getenv_int("QPGPU_STREAMS", 2); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
+  int workers = getenv_int("QPGPU_STREAMS", 4); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
   std::atomic<size_t> next(0); std::atomic<int> first_rc(0); std::mutex emu; std::string emsg;
   auto body = [&]() {
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
