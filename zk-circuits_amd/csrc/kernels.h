@@ -60,7 +60,7 @@ int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t
 void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s);
 // Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to
 // 2^cap_height digests. Returns (host-side) nothing; layout helper below.
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0, bool shared_gpu = false);
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0, bool batch = false);
 static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
   size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
 }

@@ -297,12 +297,15 @@ __global__ void __launch_bounds__(16 * G) k_levels_coop_fused(const u64* __restr
   }
 }
 static constexpr size_t COOP_MAX_PARENTS = 16384;
-void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done, bool shared_gpu) {
-  // (Tried for batch mode: per-lane kernels down to 2048 parents, because the 16-lane form costs ~3x the instructions per
-  // permutation. Stream-pipelined throughput did not improve — 257-278 vs 285 proofs/s — the longer per-proof critical path
-  // costs more overlap than the saved instructions buy, so both modes use the same thresholds.)
-  (void)shared_gpu;
-  static const size_t pair_max = (size_t)getenv_int_m("QPGPU_PAIR_MAX", (int)PAIR_MAX_LEAVES), coop_max = (size_t)getenv_int_m("QPGPU_COOP_MAX", (int)COOP_MAX_PARENTS);   // env: tuning experiments
+void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done, bool batch) {
+  // The 2-lane form for 32 K / 64 K parents, the 16-lane form from 16 K parents down (lowest latency) — in batches too: the
+  // 16-lane form costs 2.8x and the 2-lane form 1.4x the instructions of one permutation per lane (tools/valu_budget.py) and
+  // batches are VALU-bound, yet per-lane levels down to 4 K parents measured 341-344 vs 356-369 proofs/s (medians of 9 batches
+  // of 48, four worker streams): the longer critical path of every proof costs more overlap than the saved instructions buy.
+  (void)batch;
+  static const int env_pair = getenv_int_m("QPGPU_PAIR_MAX", -1), env_coop = getenv_int_m("QPGPU_COOP_MAX", -1);   // tuning overrides
+  const size_t pair_max = env_pair >= 0 ? (size_t)env_pair : PAIR_MAX_LEAVES;
+  const size_t coop_max = env_coop >= 0 ? (size_t)env_coop : COOP_MAX_PARENTS;
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
   for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {

@@ -233,7 +233,7 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
   if (fork_late) fork();
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
-    merkle_levels(dig, N, c->cap_h, s, done, w->shared_gpu); }
+    merkle_levels(dig, N, c->cap_h, s, done, w->batch_mode); }
 }
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
                           u64 salt_seed, const u64* salts_host, hipStream_t s) {
@@ -636,7 +636,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
       ProfScope ps(w, s, PF_FRI_LAYERS, 8.0 * (2 * nl + 2 * Nl * 2 + 12 * leaves));
       lde_batch(w->fri_coeffs[l], nl, w->fri_vals[l], Nl, 2, lg, c->rate, l == 0 ? c->d_lde_scale : c->d_fri_scale[l], c->pl, s, w->shared_gpu);
       merkle_leaves_fri(w->fri_vals[l], w->fri_vals[l] + Nl, c->arity[l], leaves, w->fri_dig[l], s);
-      merkle_levels(w->fri_dig[l], leaves, c->cap_h, s, 0, w->shared_gpu);
+      merkle_levels(w->fri_dig[l], leaves, c->cap_h, s, 0, w->batch_mode);
     }
     { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->fri_dig[l], leaves), capn * 4); if (rc_) return rc_; }
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
