@@ -80,6 +80,7 @@ struct CircuitDev {            // passed by value to kernels
   int num_gate_constraints;
   GateDev gates[MAX_GATES];
   const u64* k_is;             // device, [num_routed]
+  const u64* l0_lde;           // device, [N] leaf order: L_0(x) = (x^n - 1) / (n (x - 1)) on the LDE coset (circuit constant; null: computed per point)
   u64 coset_w[16], coset_dom[16]; // CosetInterpolationGate: barycentric weights and the subgroup points (one such gate per circuit)
 };
 struct Chal2 { u64 v[2]; };
@@ -90,6 +91,8 @@ void zpp_compute(const CircuitDev& cd, const u64* wires_vals, const u64* sigma_v
                  u64* zpp_vals, const NttPlan& pl, hipStream_t s);
 static inline size_t zpp_scratch_elems(int nch, size_t n, int npp) { return (size_t)nch * n * (npp + 2) + (size_t)nch * (n / 512 + 2); }
 
+// L_0 on the LDE coset, leaf order: out[N]. One Fermat inversion per point, done once per circuit instead of once per proof and point.
+void l0_table(const CircuitDev& cd, u64* out, const NttPlan& pl, hipStream_t s);
 // alpha power table: out[c][i] = alpha_c^i, i < count
 void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
 // Quotient values (row a8) on the LDE coset in leaf order: out [nch][N]. cs_lde [S][N], wires_lde [.][N] (stride N), zs_lde [.][N].

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   // ---- L0(x) (Z_c(x) - 1)
   if (PART != 2) {
     u64 zhx = zh.zh[j & ((1u << cd.rate_bits) - 1)];
-    u64 l0 = gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
+    const u64 l0 = cd.l0_lde ? cd.l0_lde[L] : gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
     for (int c = 0; c < nch; c++) {
       u64 t = gl_mul(l0, gl_sub(zl[(size_t)c * N + L], 1));
       tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
@@ -448,6 +448,19 @@ __global__ void __launch_bounds__(256) k_quotient_sum(int log_N, int rate_bits, 
   for (int c = 0; c < nch; c++) out[(size_t)c * N + L] = gl_mul(gl_add(a[(size_t)c * N + L], b[(size_t)c * N + L]), zi);
 }
 
+__global__ void __launch_bounds__(256) k_l0_table(int log_n, int rate_bits, Zh8 zh, u64 n_inv, u64* __restrict__ out, const u64* __restrict__ rt, int log_M) {
+  const int log_N = log_n + rate_bits;
+  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (L >= (size_t(1) << log_N)) return;
+  const u32 j = rev_bits((u32)L, log_N);
+  const u64 x = gl_mul(GL_GEN, root_pow_d(rt, log_M, (u64)j << (log_M - log_N)));
+  out[L] = gl_mul(zh.zh[j & ((1u << rate_bits) - 1)], gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
+}
+static Zh8 quotient_zh(const CircuitDev& cd);
+void l0_table(const CircuitDev& cd, u64* out, const NttPlan& pl, hipStream_t s) {
+  const size_t n = size_t(1) << cd.log_n, N = n << cd.rate_bits;
+  hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd.log_n, cd.rate_bits, quotient_zh(cd), gl_inv((u64)n), out, pl.rt, pl.log_M);
+}
 static Zh8 quotient_zh(const CircuitDev& cd) {
   Zh8 zh; const size_t n = size_t(1) << cd.log_n;
   u64 gn = gl_pow(GL_GEN, n), w = gl_root(cd.rate_bits), t = 1;

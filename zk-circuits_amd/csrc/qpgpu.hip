@@ -82,7 +82,7 @@ struct qpgpu_circuit {
   CircuitDev cd; NttPlan pl;
   int log_n, log_N, rate, S, W, Zp, Q, salt, nch, cap_h, nlayers; size_t n, N;
   int arity[MAX_FRI_LAYERS]; int fri_log_n[MAX_FRI_LAYERS + 1];   // log2 of coefficient count at each layer
-  u64 *d_rt = nullptr, *d_lde_scale = nullptr, *d_qpost = nullptr, *d_kis = nullptr;
+  u64 *d_rt = nullptr, *d_lde_scale = nullptr, *d_qpost = nullptr, *d_kis = nullptr, *d_l0 = nullptr;
   u64* d_fri_scale[MAX_FRI_LAYERS + 1] = {nullptr};
   u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_dig = nullptr;
   std::vector<u64> cs_cap;
@@ -280,7 +280,7 @@ void qpgpu_circuit_destroy(qpgpu_circuit* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (Workspace* w : c->free_ws) ws_destroy(w);
-  for (u64* p : {c->d_rt, c->d_lde_scale, c->d_qpost, c->d_kis, c->d_cs_vals, c->d_cs_coeffs, c->d_cs_lde, c->d_cs_dig}) if (p) (void)hipFree(p);
+  for (u64* p : {c->d_rt, c->d_lde_scale, c->d_qpost, c->d_kis, c->d_l0, c->d_cs_vals, c->d_cs_coeffs, c->d_cs_lde, c->d_cs_dig}) if (p) (void)hipFree(p);
   for (int l = 0; l <= MAX_FRI_LAYERS; l++) if (c->d_fri_scale[l]) (void)hipFree(c->d_fri_scale[l]);
   delete c;
 }
@@ -399,6 +399,10 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
     if (!(t == QPGPU_GATE_NOOP || t == QPGPU_GATE_CONSTANT || t == QPGPU_GATE_PUBLIC_INPUT || t == QPGPU_GATE_BASESUM2 || t == QPGPU_GATE_ARITHMETIC || t == QPGPU_GATE_POSEIDON))
       c->leaf_gates_only = false;
   }
+  // L_0 on the LDE coset (circuit constant; filled once the root table exists, below)
+  CC_TRY(hipMalloc((void**)&c->d_l0, N * 8));
+  l0_table(c->cd, c->d_l0, c->pl, s);
+  c->cd.l0_lde = getenv_int("QPGPU_L0_TABLE", 1) ? c->d_l0 : nullptr;      // 0: recompute L_0 per point (A/B switch)
   // preprocessed oracle: constants/sigmas values -> coeffs -> LDE -> Merkle (kept resident)
   CC_TRY(hipMalloc((void**)&c->d_cs_vals, (size_t)c->S * n * 8));
   CC_TRY(hipMalloc((void**)&c->d_cs_coeffs, (size_t)c->S * n * 8));

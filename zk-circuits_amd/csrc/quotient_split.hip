@@ -121,26 +121,34 @@ __global__ void __launch_bounds__(256) k_perm_terms(CircuitDev cd, const u64* __
   const int NC = cd.num_constants, R = cd.num_routed, nch = cd.num_challenges, npp = cd.num_pp, deg = cd.qdf;
   int term = 0;
   {
-    u64 zhx = zh.zh[j & ((1u << cd.rate_bits) - 1)];
-    u64 l0 = gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
+    const u64 zhx = zh.zh[j & ((1u << cd.rate_bits) - 1)];
+    const u64 l0 = cd.l0_lde ? cd.l0_lde[L] : gl_mul(zhx, gl_mul(n_inv, gl_inv(gl_sub(x, 1))));
     for (int c = 0; c < nch; c++) Pm[(size_t)(term++) * N + L] = gl_mul(l0, gl_sub(zl[(size_t)c * N + L], 1));
   }
-  // both challenges share the loads of w_j and sigma_j
-  u64 prev[2], bx[2];
+  // both challenges share the loads of w_j and sigma_j; a chunk's loads are issued together; factors and running products are lazy
+  // residues (same arithmetic as the fused kernel in plonk.hip), canonicalised when a term is stored
+  u64 prev[2] = {0, 0}, bx[2] = {0, 0};
   for (int c = 0; c < nch; c++) { prev[c] = zl[(size_t)c * N + L]; bx[c] = gl_mul(betas.v[c], x); }
   for (int k = 0; k <= npp; k++) {
     u64 nu[2] = {1, 1}, de[2] = {1, 1};
-    for (int jj = k * deg; jj < (k + 1) * deg && jj < R; jj++) {
-      const u64 w = wl[(size_t)jj * N + L], sg = cs[(size_t)(NC + jj) * N + L], kj = cd.k_is[jj];
+    u64 wv[8], sgv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int jj = k * deg + u; const bool ok = u < deg && jj < R; wv[u] = ok ? wl[(size_t)jj * N + L] : 0; sgv[u] = ok ? cs[(size_t)(NC + jj) * N + L] : 0; }
+    u64 nxt[2];
+    for (int c = 0; c < nch; c++) nxt[c] = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int jj = k * deg + u;
+      if (!(u < deg && jj < R)) continue;
+      const u64 w = wv[u], sg = sgv[u], kj = cd.k_is[jj];
       for (int c = 0; c < nch; c++) {
-        nu[c] = gl_mul(nu[c], gl_add(gl_add(w, gl_mul(bx[c], kj)), gammas.v[c]));
-        de[c] = gl_mul(de[c], gl_add(gl_add(w, gl_mul(betas.v[c], sg)), gammas.v[c]));
+        nu[c] = mul_lazy(nu[c], add_lazy_canon(add_lazy_canon(mul_lazy(bx[c], kj), w), gammas.v[c]));
+        de[c] = mul_lazy(de[c], add_lazy_canon(add_lazy_canon(mul_lazy(betas.v[c], sg), w), gammas.v[c]));
       }
     }
     for (int c = 0; c < nch; c++) {
-      u64 next = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
-      Pm[(size_t)(nch + c * (npp + 1) + k) * N + L] = gl_sub(gl_mul(prev[c], nu[c]), gl_mul(next, de[c]));
-      prev[c] = next;
+      Pm[(size_t)(nch + c * (npp + 1) + k) * N + L] = gl_sub(canon(mul_lazy(prev[c], nu[c])), canon(mul_lazy(nxt[c], de[c])));
+      prev[c] = nxt[c];
     }
   }
 }
