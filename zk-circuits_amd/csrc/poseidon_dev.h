@@ -205,12 +205,11 @@ __device__ __forceinline__ void coop_init(CoopCtx& cx, int i) {
   for (int j = 0; j < 12; j++) cx.m[j] = C[(j - ii + 12) % 12] + ((ii == 0 && j == 0) ? 8u : 0u);
 }
 // x: this lane's element (canonical or lazy in; canonical out). All 64 lanes of the wave must call this.
-// `xch` points at TWO 12-slot exchange buffers (24 u64) used alternately, so one barrier per round suffices (a wave-scope
-// fence with volatile LDS accesses was measured 40 % SLOWER than s_barrier here: it serialises the twelve ds_reads).
+// `xch` points at TWO 12-slot exchange buffers (24 u64) used alternately, so one wave-local hand-off (COOP_SYNC) per round
+// suffices. (volatile LDS accesses instead of the fence were measured 40 % slower: they serialise the twelve ds_reads.)
 // The round loop stays rolled (30 x ~150 instructions); the next round's constant is a plain global load issued a full
 // round ahead, so its latency hides behind the S-box. (Keeping the 30 per-lane constants in a register array made the
 // compiler spill them to scratch once the loop was not unrolled: 296 B/lane of scratch traffic on the critical path.)
-#if !defined(QPGPU_COOP_DPP)
 __device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64* xch) {
   const u64* __restrict__ rcl = POSEIDON_RC_DEV + cx.ii;
   x = add_lazy_canon(x, rcl[0]);
@@ -233,46 +232,6 @@ __device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64
   return canon(x);
 }
 
-#else
-// DPP form (compile with -DQPGPU_COOP_DPP; measured SLOWER than the LDS exchange, 0.262 vs 0.227 ms for a 2^17-leaf tree's levels:
-// the compiler keeps the S-box chain and the broadcasts in program order and a wave issues in order, so the intended overlap does
-// not happen and the 24 DPP moves only lengthen the stream). The 16 lanes of a group are one DPP row, so row_newbcast:j hands every lane element j without LDS or any
-// barrier. In a partial round every lane applies the S-box to the broadcast element 0 itself (redundant, but a lone wave is bound
-// by dependent-issue latency, not by instruction count), so the other eleven broadcasts and their 22 multiply-adds are independent
-// of the S-box chain and fill its stall slots: the round's critical path is S-box + 2 multiply-adds + fold instead of
-// S-box + exchange + 12-deep accumulation. Two accumulator chains per half keep the accumulation itself short.
-template <int J> __device__ __forceinline__ u32 row_bcast(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xF, 0xF, false); }
-template <int J> struct CoopAcc {
-  static __device__ __forceinline__ void run(u32 lo, u32 hi, const CoopCtx& cx, u64 (&sl)[2], u64 (&sh)[2]) {
-    const u32 vl = row_bcast<J>(lo), vh = row_bcast<J>(hi);
-    sl[J & 1] = mad32(vl, cx.m[J], sl[J & 1]); sh[J & 1] = mad32(vh, cx.m[J], sh[J & 1]);
-    CoopAcc<J + 1>::run(lo, hi, cx, sl, sh);
-  }
-};
-template <> struct CoopAcc<12> { static __device__ __forceinline__ void run(u32, u32, const CoopCtx&, u64 (&)[2], u64 (&)[2]) {} };
-__device__ __forceinline__ u64 coop_permute(u64 x, int i, const CoopCtx& cx, u64* xch) {
-  (void)i; (void)xch;
-  const u64* __restrict__ rcl = POSEIDON_RC_DEV + cx.ii;
-  x = add_lazy_canon(x, rcl[0]);
-  u64 c_next = rcl[12];
-  for (int r = 0; r < 30; r++) {
-    const bool full = r < 4 || r >= 26;
-    const u64 c = r + 1 < 30 ? c_next : 0;
-    c_next = r + 2 < 30 ? rcl[12 * (r + 2)] : 0;      // prefetch
-    u64 sl[2] = {(u32)c, 0}, sh[2] = {c >> 32, 0};
-    if (full) {
-      x = sbox7_lazy(x);
-      CoopAcc<0>::run((u32)x, (u32)(x >> 32), cx, sl, sh);
-    } else {
-      const u32 lo = (u32)x, hi = (u32)(x >> 32);
-      const u64 x0 = sbox7_lazy(pack64(row_bcast<0>(lo), row_bcast<0>(hi)));
-      CoopAcc<1>::run(lo, hi, cx, sl, sh);
-      sl[0] = mad32((u32)x0, cx.m[0], sl[0]); sh[0] = mad32((u32)(x0 >> 32), cx.m[0], sh[0]);
-    }
-    x = mds_row_fold(sl[0] + sl[1], sh[0] + sh[1]);
-  }
-  return canon(x);
-}
-#endif
+// (A DPP row_newbcast exchange instead of LDS was measured slower: profiles/r01_notes_ab_experiments.md.)
 
 } // namespace qp
