@@ -150,6 +150,7 @@ struct GatherFri { const u64* a; const u64* b; const u64* digests; int arity_bit
 struct GatherArgs {
   GatherTree trees[4]; int log_N, cap_height, num_layers; GatherFri layers[MAX_FRI_LAYERS];
   u32 idx[MAX_QUERIES]; int nq; size_t bytes_per_query;
+  u64* pow_reset;              // if set: re-arm the workspace's PoW result slot (atomicMin target) for the next proof
 };
 void query_gather(const GatherArgs& a, uint8_t* out, hipStream_t s);
 

@@ -65,6 +65,7 @@ struct Workspace {
   u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
   u64 pub_seq = 0;
   bool shared_gpu = false;    // opt-in (QPGPU_SHARED_MODE=1): kernel choices that assume other proofs fill the chip
+  bool pow_armed = false;     // pow_result holds ~0 (re-armed by the last proof's gather kernel)
   bool batch_mode = false;    // set for workers of qpgpu_prove_batch when several proofs share the chip: fused quotient kernel
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
@@ -664,7 +665,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     for (int i = 0; i < ch.n_in; i++) sp.s[i] = ch.in[i];
     const int pos = ch.n_in;
     u64 none = ~0ULL; pow_witness = none;
-    HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s));
+    // the result slot is re-armed by the previous proof's query_gather; an explicit reset only after workspace creation or an aborted proof
+    if (!w->pow_armed) { HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
+    w->pow_armed = false;
     u64 base = 0, span = 1ULL << 17;
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
@@ -692,11 +695,12 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const size_t Nl = size_t(1) << (c->fri_log_n[l] + c->rate);
     ga.layers[l] = GatherFri{w->fri_vals[l], w->fri_vals[l] + Nl, w->fri_dig[l], c->arity[l], c->fri_log_n[l] + c->rate - c->arity[l]};
   }
-  ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query;
+  ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query; ga.pow_reset = w->pow_result;
   for (int q = 0; q < ga.nq; q++) ga.idx[q] = (u32)(ch.challenge() % N);
   { ProfScope ps(w, s, PF_GATHER, 2.0 * L.bytes_per_query * ga.nq); query_gather(ga, w->query_bytes, s); }
   { int rc_ = fetch_to_host(w, s, (const u64*)w->query_bytes, (L.bytes_per_query * ga.nq + 7) / 8); if (rc_) return rc_; }
   HIP_TRY(hipGetLastError());
+  w->pow_armed = true;            // the gather kernel has run (its bytes arrived), so the slot holds ~0 again
   memcpy(out + L.queries_off, pin, L.bytes_per_query * ga.nq);
   { u64 npi = d.num_public_inputs; memcpy(out + L.pis_off, &npi, 8); memcpy(out + L.pis_off + 8, pis, 8 * npi); }
   mark();
