@@ -21,7 +21,7 @@ typedef struct qpsynth_params {
   uint32_t fri_num_layers; uint32_t fri_arity_bits[8];
   uint64_t circuit_seed;
   uint32_t fri_cap_height, fri_num_queries, fri_pow_bits;   /* 0 = preset default (4, 28, 16); pow_bits uses 0xFFFFFFFF for "0 bits" */
-  uint32_t reserved;
+  uint32_t reserved;                       /* 1: recursion gates with the second parameter set (preset "RT2") */
   /* rows of the recursive-verifier gate set (all zero: leaf gate set only), in order ArithmeticExtension, MulExtension, Reducing,
    * ReducingExtension, RandomAccess{4}, PoseidonMds, Exponentiation, CosetInterpolation{4} — SURVEY.md App. D */
   uint32_t n_recursion[8];
@@ -30,7 +30,7 @@ typedef struct qpsynth_params {
 typedef struct qpsynth_circuit qpsynth_circuit;
 
 /* Presets: "A" leaf non-zk k=13, "B" leaf zk k=14, "V" voting-shaped k=20, "T" tiny k=6 test circuit,
- * "R" / "RT" recursion-shaped (all 14 gate types) k=13 / k=8. */
+ * "R" / "RT" recursion-shaped (all 14 gate types) k=13 / k=8, "RT2" = RT with other gate parameters. */
 int qpsynth_preset(const char* name, qpsynth_params* out);
 int qpsynth_circuit_create(const qpsynth_params* p, qpsynth_circuit** out);
 void qpsynth_circuit_destroy(qpsynth_circuit* c);

@@ -33,7 +33,7 @@ def circuits():
 
 # "RT"/"R": recursion-shaped circuits carrying all 14 gate types of the in-circuit verifier behind aggregate()
 # (tree.rs:106-143) — parity is GPU == oracle; parity with the Rust prover is unpinned for those gates.
-@pytest.mark.parametrize("preset", ["T", "TZ", "A", "B", "RT", "R"])
+@pytest.mark.parametrize("preset", ["T", "TZ", "A", "B", "RT", "RT2", "R"])
 def test_proof_bytes_match_oracle(circuits, preset):
     sc, oc, gc = circuits(preset)
     assert np.array_equal(gc.cap(), oc.cap())                       # preprocessed commitment

@@ -104,12 +104,14 @@ def test_oracle_prove_verify_on_varied_shapes(shape):
 # base-field evaluator (prover) and the extension-algebra evaluator (verifier) agree and that every gate wire is constrained.
 REC_KINDS = ["ArithmeticExtension", "MulExtension", "Reducing", "ReducingExtension", "RandomAccess", "PoseidonMds",
              "Exponentiation", "CosetInterpolation"]
-REC_USED_WIRES = [80, 78, 133, 132, 90, 48, 134, 47]
+REC_USED_WIRES = {"RT": [80, 78, 133, 132, 90, 48, 134, 47],      # standard_recursion_config parameters
+                  "RT2": [56, 54, 55, 48, 41, 48, 44, 35]}        # second parameter set (7/9 ops, 17/11 coeffs, RA{2,5,1}, 21 bits, coset{3,3})
+RA_SHAPE = {"RT": (4, 4), "RT2": (2, 5)}                          # RandomAccess (bits, copies)
 
 
-@pytest.fixture(scope="module")
-def rec_tiny():
-    sc = SynthCircuit("RT"); return sc, OracleCircuit(sc.desc)
+@pytest.fixture(scope="module", params=["RT", "RT2"])
+def rec_tiny(request):
+    sc = SynthCircuit(request.param); sc.preset = request.param; return sc, OracleCircuit(sc.desc)
 
 
 def rec_first_row(sc, kind):
@@ -120,8 +122,11 @@ def rec_first_row(sc, kind):
 def test_recursion_gate_set_selectors_follow_upstream_grouping(rec_tiny):
     sc, _ = rec_tiny
     d = sc.desc
-    assert d.num_gates == 14 and d.num_selector_groups == 5 and d.num_constants == 7
-    assert [d.selector_group_ranges[i] for i in range(10)] == [0, 6, 6, 10, 10, 12, 12, 13, 13, 14]
+    assert d.num_gates == 14
+    want = {"RT": [0, 6, 6, 10, 10, 12, 12, 13, 13, 14],          # degrees 0,1,1,1,2,2 | 2,3,3,3 | 4,5 | 6 | 7
+            "RT2": [0, 6, 6, 11, 11, 13, 13, 14]}[sc.preset]       # degrees 0,1,1,1,2,2 | 2,3,3,3,3 | 3,4 | 7
+    assert [d.selector_group_ranges[i] for i in range(2 * d.num_selector_groups)] == want
+    assert d.num_constants == d.num_selector_groups + 2
 
 
 def test_recursion_gates_witness_prove_verify(rec_tiny):
@@ -137,8 +142,9 @@ def test_recursion_gate_constrains_every_wire(rec_tiny, kind):
     sc, oc = rec_tiny
     w, p = sc.witness(4)
     row = rec_first_row(sc, kind)
-    for col in range(REC_USED_WIRES[kind]):
-        if kind == 4 and col < 72 and col % 18 >= 2 and col % 18 - 2 != int(w[col - col % 18, row]):
+    bits, copies = RA_SHAPE[sc.preset]; stride = 2 + (1 << bits)
+    for col in range(REC_USED_WIRES[sc.preset][kind]):
+        if kind == 4 and col < stride * copies and col % stride >= 2 and col % stride - 2 != int(w[col - col % stride, row]):
             continue                                         # RandomAccess: list items other than list[index] are free
         w2 = w.copy(); w2[col, row] = (int(w2[col, row]) + 1) % P
         assert check_witness(oc, w2, p) is not None, "wire %d of a %s row is unconstrained" % (col, REC_KINDS[kind])

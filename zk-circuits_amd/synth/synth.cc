@@ -34,7 +34,13 @@ const KindInfo KINDS[K_KINDS] = {
   {QPGPU_GATE_ARITHMETIC_EXTENSION, 10, 0, 0, 3}, {QPGPU_GATE_MUL_EXTENSION, 13, 0, 0, 3}, {QPGPU_GATE_REDUCING, 43, 0, 0, 2},
   {QPGPU_GATE_REDUCING_EXTENSION, 32, 0, 0, 2}, {QPGPU_GATE_RANDOM_ACCESS, 4, 4, 2, 5}, {QPGPU_GATE_POSEIDON_MDS, 0, 0, 0, 1},
   {QPGPU_GATE_EXPONENTIATION, 66, 0, 0, 4}, {QPGPU_GATE_COSET_INTERPOLATION, 4, 6, 0, 6}};
-const int COSET_BITS = 4, COSET_DEG = 6, COSET_NP = 16, COSET_NI = (COSET_NP - 2) / (COSET_DEG - 1);
+// second parameter set (qpsynth_params.reserved = 1): smaller gates, so that the evaluators' parametrisation is exercised
+const KindInfo KINDS_ALT[K_KINDS] = {
+  {QPGPU_GATE_NOOP, 0, 0, 0, 0}, {QPGPU_GATE_CONSTANT, 2, 0, 0, 1}, {QPGPU_GATE_PUBLIC_INPUT, 0, 0, 0, 1}, {QPGPU_GATE_BASESUM2, 63, 0, 0, 2},
+  {QPGPU_GATE_ARITHMETIC, 20, 0, 0, 3}, {QPGPU_GATE_POSEIDON, 0, 0, 0, 7},
+  {QPGPU_GATE_ARITHMETIC_EXTENSION, 7, 0, 0, 3}, {QPGPU_GATE_MUL_EXTENSION, 9, 0, 0, 3}, {QPGPU_GATE_REDUCING, 17, 0, 0, 2},
+  {QPGPU_GATE_REDUCING_EXTENSION, 11, 0, 0, 2}, {QPGPU_GATE_RANDOM_ACCESS, 2, 5, 1, 3}, {QPGPU_GATE_POSEIDON_MDS, 0, 0, 0, 1},
+  {QPGPU_GATE_EXPONENTIATION, 21, 0, 0, 4}, {QPGPU_GATE_COSET_INTERPOLATION, 3, 3, 0, 3}};
 
 struct E2 { u64 a, b; };   // F_{p^2} = F_p[X]/(X^2 - 7)
 inline E2 e_add(E2 x, E2 y) { return {gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
@@ -55,6 +61,7 @@ struct qpsynth_circuit {
   int nsel = 2, NC = 4;                      // selector columns, total constant columns (selectors + 2)
   int gate_index[K_KINDS];                   // position of each row kind's gate in the gate list (-1: absent)
   std::vector<u64> coset_weights, coset_dom;
+  KindInfo kinds[K_KINDS];                   // gate parameters in use (KINDS or KINDS_ALT)
   // copy constraints, in application order: value[tgt] = value[src]
   std::vector<Cell> copy_src, copy_tgt;      // phase-2 (arith inputs) first, then phase-3 (free cells)
   size_t n_phase2 = 0;
@@ -88,9 +95,10 @@ int qpsynth_preset(const char* name, qpsynth_params* o) {
   } else if (s == "TZ") {
     o->degree_bits = 7; o->zero_knowledge = 1; o->n_poseidon = 6; o->n_basesum = 12; o->n_arith = 16; o->n_constant = 3; o->n_copies = 150;
     o->fri_num_layers = 1; o->fri_arity_bits[0] = 4; o->circuit_seed = 0x5157C1C0ULL + 7;
-  } else if (s == "R" || s == "RT") {
+  } else if (s == "R" || s == "RT" || s == "RT2") {
     // recursion-shaped: every gate of the in-circuit verifier (aggregate(), tree.rs:106-143) next to the leaf set
-    const bool tiny = s == "RT";
+    const bool tiny = s != "R";
+    if (s == "RT2") o->reserved = 1;                     // second gate-parameter set (KINDS_ALT)
     o->degree_bits = tiny ? 8 : 13; o->zero_knowledge = 0;
     uint32_t m = tiny ? 1 : 40;
     o->n_poseidon = 12 * m; o->n_basesum = 8 * m; o->n_arith = 12 * m; o->n_constant = 3 * m; o->n_copies = 300 * m;
@@ -123,12 +131,15 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   for (uint32_t i = 0; i < p.n_arith; i++) c->kind[r++] = K_ARITH;
   for (uint32_t i = 0; i < p.n_constant; i++) c->kind[r++] = K_CONST;
   for (int k = 0; k < 8; k++) for (uint32_t i = 0; i < p.n_recursion[k]; i++) c->kind[r++] = (uint8_t)(K_ARITH_EXT + k);
+  for (int k = 0; k < K_KINDS; k++) c->kinds[k] = (p.reserved == 1 ? KINDS_ALT : KINDS)[k];
+  const KindInfo* KI = c->kinds;
+  const int COSET_BITS = (int)KI[K_COSET].param, COSET_NP = 1 << COSET_BITS;
   // ---- gate list: kinds in use, ordered by constraint degree; selector groups as upstream forms them
   // (a group grows while group_size + next_gate_degree < max_degree = 8). The leaf set gives [0,5),[5,6) as in common.bin.
   {
     std::vector<int> kinds;
     for (int k = 0; k < K_KINDS; k++) if (k <= K_POSEIDON || (n_rec && p.n_recursion[k - K_ARITH_EXT])) kinds.push_back(k);
-    std::stable_sort(kinds.begin(), kinds.end(), [](int a, int b) { return KINDS[a].degree < KINDS[b].degree; });
+    std::stable_sort(kinds.begin(), kinds.end(), [KI](int a, int b) { return KI[a].degree < KI[b].degree; });
     for (int k = 0; k < K_KINDS; k++) c->gate_index[k] = -1;
     for (size_t i = 0; i < kinds.size(); i++) c->gate_index[kinds[i]] = (int)i;
     if (kinds.size() > 16) { delete c; return fail("too many gates"); }
@@ -137,12 +148,12 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
     size_t start = 0; c->sel_idx.assign(kinds.size(), 0);
     while (start < kinds.size()) {
       size_t size = 0;
-      while (start + size < kinds.size() && (int)size + KINDS[kinds[start + size]].degree < 8) size++;
+      while (start + size < kinds.size() && (int)size + KI[kinds[start + size]].degree < 8) size++;
       for (size_t i = 0; i < size; i++) c->sel_idx[start + i] = (uint32_t)(c->groups.size() / 2);
       c->groups.push_back((uint32_t)start); c->groups.push_back((uint32_t)(start + size)); start += size;
     }
     for (int k : kinds) {
-      qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = KINDS[k].tag; g.param = KINDS[k].param; g.param2 = KINDS[k].p2; g.param3 = KINDS[k].p3;
+      qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = KI[k].tag; g.param = KI[k].param; g.param2 = KI[k].p2; g.param3 = KI[k].p3;
       if (k == K_COSET) { g.table = c->coset_weights.data(); g.table_len = COSET_NP; }
       c->gates.push_back(g);
     }
@@ -226,6 +237,7 @@ int qpsynth_circuit_create(const qpsynth_params* pp, qpsynth_circuit** out) {
   // Synthetic digest (the real one hashes the constants/sigmas cap + common data; any 4 felts serve the transcript).
   { u64 t[16] = {p.circuit_seed % GL_P, p.degree_bits, p.zero_knowledge, p.n_poseidon, p.n_basesum, p.n_arith, p.n_constant, p.n_copies};
     for (int i = 0; i < 8; i++) t[8 + i] = p.n_recursion[i];
+    t[8] += (u64)p.reserved << 32;
     hash_no_pad(t, n_rec ? 16 : 8, d.circuit_digest); }
   *out = c; return 0;
 }
@@ -271,6 +283,7 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
   memset(wires, 0, sizeof(u64) * (size_t)W * n);
   const u64* cs = c->constants_sigmas.data();
   const int nsel = c->nsel;
+  const KindInfo* KI = c->kinds;
   auto Wr = [&](size_t row, int col) -> u64& { return wires[(size_t)col * n + row]; };
   auto LC = [&](size_t row, int i) -> u64 { return cs[(size_t)(nsel + i) * n + row]; };
   auto rext = [&]() -> E2 { E2 e; e.a = rng.felt(); e.b = rng.felt(); return e; };
@@ -288,20 +301,20 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
       case K_BASESUM: { u64 v = rng.next() >> 1; Wr(row, 0) = v; for (int l = 0; l < 63; l++) Wr(row, 1 + l) = (v >> l) & 1; break; }
       case K_CONST: Wr(row, 0) = LC(row, 0); Wr(row, 1) = LC(row, 1); break;
       case K_ARITH_EXT:
-        for (int op = 0; op < 10; op++) {
+        for (int op = 0; op < (int)KI[K_ARITH_EXT].param; op++) {
           E2 m0 = rext(), m1 = rext(), ad = rext();
           putx(row, 8 * op, m0); putx(row, 8 * op + 2, m1); putx(row, 8 * op + 4, ad);
           putx(row, 8 * op + 6, e_add(e_scale(e_mul(m0, m1), LC(row, 0)), e_scale(ad, LC(row, 1))));
         }
         break;
       case K_MUL_EXT:
-        for (int op = 0; op < 13; op++) {
+        for (int op = 0; op < (int)KI[K_MUL_EXT].param; op++) {
           E2 m0 = rext(), m1 = rext();
           putx(row, 6 * op, m0); putx(row, 6 * op + 2, m1); putx(row, 6 * op + 4, e_scale(e_mul(m0, m1), LC(row, 0)));
         }
         break;
       case K_REDUCING: case K_REDUCING_EXT: {
-        const bool xc = c->kind[row] == K_REDUCING_EXT; const int nc = xc ? 32 : 43, start_accs = 6 + (xc ? 2 : 1) * nc;
+        const bool xc = c->kind[row] == K_REDUCING_EXT; const int nc = (int)KI[xc ? K_REDUCING_EXT : K_REDUCING].param, start_accs = 6 + (xc ? 2 : 1) * nc;
         E2 alpha = rext(), acc = rext();
         putx(row, 2, alpha); putx(row, 4, acc);
         for (int i = 0; i < nc; i++) {
@@ -311,16 +324,19 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
         }
         break;
       }
-      case K_RANDOM_ACCESS:
-        for (int cp = 0; cp < 4; cp++) {
-          const int base = 18 * cp; u64 idx = rng.below(16);
+      case K_RANDOM_ACCESS: {
+        const int bits = (int)KI[K_RANDOM_ACCESS].param, copies = (int)KI[K_RANDOM_ACCESS].p2, extra = (int)KI[K_RANDOM_ACCESS].p3, vec = 1 << bits;
+        const int routed = (2 + vec) * copies + extra;
+        for (int cp = 0; cp < copies; cp++) {
+          const int base = (2 + vec) * cp; u64 idx = rng.below(vec);
           Wr(row, base) = idx;
-          for (int i = 0; i < 16; i++) Wr(row, base + 2 + i) = rng.felt();
+          for (int i = 0; i < vec; i++) Wr(row, base + 2 + i) = rng.felt();
           Wr(row, base + 1) = Wr(row, base + 2 + (int)idx);
-          for (int i = 0; i < 4; i++) Wr(row, 74 + 4 * cp + i) = (idx >> i) & 1;
+          for (int i = 0; i < bits; i++) Wr(row, routed + bits * cp + i) = (idx >> i) & 1;
         }
-        Wr(row, 72) = LC(row, 0); Wr(row, 73) = LC(row, 1);
+        for (int i = 0; i < extra; i++) Wr(row, (2 + vec) * copies + i) = LC(row, i);
         break;
+      }
       case K_POSEIDON_MDS: {
         u64 a[12], b[12];
         for (int i = 0; i < 12; i++) { a[i] = rng.felt(); b[i] = rng.felt(); Wr(row, 2 * i) = a[i]; Wr(row, 2 * i + 1) = b[i]; }
@@ -329,7 +345,7 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
         break;
       }
       case K_EXP: {
-        const int nb = 66; u64 base = rng.felt(), prev = 1;
+        const int nb = (int)KI[K_EXP].param; u64 base = rng.felt(), prev = 1;
         Wr(row, 0) = base;
         for (int i = 0; i < nb; i++) Wr(row, 1 + i) = rng.next() & 1;
         for (int i = 0; i < nb; i++) {
@@ -340,9 +356,10 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
         break;
       }
       case K_COSET: {
+        const int COSET_NP = 1 << (int)KI[K_COSET].param, COSET_DEG = (int)KI[K_COSET].p2, COSET_NI = (COSET_NP - 2) / (COSET_DEG - 1);
         const int s_point = 1 + 2 * COSET_NP, s_value = s_point + 2, s_inter = s_value + 2, s_shifted = s_inter + 4 * COSET_NI;
         u64 shift = rng.felt(); if (shift == 0) shift = 1;
-        E2 vals[COSET_NP], point = rext(), xs = e_scale(point, gl_inv(shift));
+        E2 vals[16], point = rext(), xs = e_scale(point, gl_inv(shift));
         Wr(row, 0) = shift; putx(row, s_point, point); putx(row, s_shifted, xs);
         for (int i = 0; i < COSET_NP; i++) { vals[i] = rext(); putx(row, 1 + 2 * i, vals[i]); }
         E2 ev{0, 0}, pr{1, 0};
