@@ -1,5 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see poseidon.h).
 #include "poseidon.h"
+#include "poseidon_fast_constants.h"
 #include <mutex>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -121,13 +122,47 @@ inline void mds_rc(u64 st[12], const u64* rc) {
   mds_rc_scalar(st, rc);
 }
 }
+// Fast form of the 22 partial rounds (upstream uses an algebraically equivalent one): tables derived and checked
+// by tools/gen_poseidon_fast.py; each round is one S-box, one 11-term dot product and 11 multiply-adds instead of a 12x12 MDS product.
+// s += FIRST; s[1:] = INIT*s[1:]; per round s0 = sbox(s0) + Q[t]; (s0, rest) = (25*s0 + WHAT[t].rest, rest + s0*V[t]).
+namespace {
+const u64 FAST_FIRST[12] = {QP_POSEIDON_FAST_FIRST};
+const u64 FAST_Q[22] = {QP_POSEIDON_FAST_Q};
+const u64 FAST_INIT[11][11] = {QP_POSEIDON_FAST_INIT};
+const u64 FAST_WHAT[22][11] = {QP_POSEIDON_FAST_WHAT};
+const u64 FAST_V[22][11] = {QP_POSEIDON_FAST_V};
+inline u64 addc_lazy(u64 x, u64 c) { u64 s = x + c; s += (0 - (u64)(s < c)) & EPS; return s; }
+// sum_j a[j]*x[j] + c0*x0: product halves accumulate separately, then lo + 2^64 mid + 2^128 top with 2^128 == -2^32 (mod p)
+inline u64 dot11(const u64* a, const u64* x, u64 c0, u64 x0) {
+  u128 p = (u128)c0 * x0;
+  u128 alo = (u64)p, ahi = (u64)(p >> 64);
+  for (int j = 0; j < 11; j++) { p = (u128)a[j] * x[j]; alo += (u64)p; ahi += (u64)(p >> 64); }
+  const u128 mid = (alo >> 64) + (u64)ahi;
+  const u64 top = (u64)(ahi >> 64) + (u64)(mid >> 64);
+  u64 r = red128_lazy((u64)alo, (u64)mid);
+  const u64 sub = top << 32;
+  u64 d = r - sub; if (__builtin_expect(r < sub, 0)) d += P;
+  return d;
+}
+}
 void poseidon_permute(u64 st[12]) {
   const u64* rc = poseidon_round_constants();
-  for (int i = 0; i < 12; i++) { u64 s = st[i] + rc[i]; s += (0 - (u64)(s < rc[i])) & EPS; st[i] = s; }
-  for (int r = 0; r < N_ROUNDS; r++) {
-    bool full = r < N_FULL_HALF || r >= N_FULL_HALF + N_PARTIAL;
-    if (full) for (int i = 0; i < 12; i++) st[i] = sbox_lazy(st[i]);
-    else st[0] = sbox_lazy(st[0]);
+  for (int i = 0; i < 12; i++) st[i] = addc_lazy(st[i], rc[i]);
+  for (int r = 0; r < N_FULL_HALF; r++) {
+    for (int i = 0; i < 12; i++) st[i] = sbox_lazy(st[i]);
+    mds_rc(st, r + 1 < N_FULL_HALF ? rc + 12 * (r + 1) : FAST_FIRST);
+  }
+  { u64 t[11]; for (int i = 0; i < 11; i++) t[i] = dot11(FAST_INIT[i], st + 1, 0, 0); for (int i = 0; i < 11; i++) st[1 + i] = t[i]; }
+  for (int t = 0; t < N_PARTIAL; t++) {
+    const u64 s0 = addc_lazy(sbox_lazy(st[0]), FAST_Q[t]);
+    const u64 d = dot11(FAST_WHAT[t], st + 1, 25, s0);
+    for (int j = 0; j < 11; j++) { const u128 p = (u128)s0 * FAST_V[t][j] + st[1 + j]; st[1 + j] = red128_lazy((u64)p, (u64)(p >> 64)); }
+    st[0] = d;
+  }
+  const int r0 = N_FULL_HALF + N_PARTIAL;
+  for (int i = 0; i < 12; i++) st[i] = addc_lazy(st[i], rc[12 * r0 + i]);
+  for (int r = r0; r < N_ROUNDS; r++) {
+    for (int i = 0; i < 12; i++) st[i] = sbox_lazy(st[i]);
     mds_rc(st, r + 1 < N_ROUNDS ? rc + 12 * (r + 1) : nullptr);
   }
   for (int i = 0; i < 12; i++) if (st[i] >= P) st[i] -= P;

@@ -104,15 +104,17 @@ if __name__ == "__main__":
         assert plain_permute(st, rc) == fast_permute(st, rc, first, init, Q, S)
     assert plain_permute([0] * 12, rc)[:2] == [0x3c18a9786cb0b359, 0xc4055e3364a246c3]
     assert all(S[t][0] == 25 for t in range(22)) and Q[21] == 0
-    path = os.path.join(os.path.dirname(__file__), "..", "zk-circuits_amd", "csrc", "poseidon_fast_constants.h")
     def arr(xs): return ", ".join("0x%016xULL" % x for x in xs)
-    with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_poseidon_fast.py (derivation and self-check there); do not edit.\n")
-        f.write("// Fast form of the 22 partial rounds: s += FIRST; s[1:] = INIT*s[1:]; per round s0 = sbox(s0) + Q[t];\n")
-        f.write("// (s0, rest) = (25*s0 + WHAT[t].rest, rest + s0*V[t]).\n#pragma once\n")
-        f.write("#define QP_POSEIDON_FAST_FIRST " + arr(first) + "\n")
-        f.write("#define QP_POSEIDON_FAST_Q " + arr(Q) + "\n")
-        f.write("#define QP_POSEIDON_FAST_INIT \\\n" + ", \\\n".join("  {" + arr(row) + "}" for row in init) + "\n")
-        f.write("#define QP_POSEIDON_FAST_WHAT \\\n" + ", \\\n".join("  {" + arr(S[t][1]) + "}" for t in range(22)) + "\n")
-        f.write("#define QP_POSEIDON_FAST_V \\\n" + ", \\\n".join("  {" + arr(S[t][2]) + "}" for t in range(22)) + "\n")
-    print("wrote", path)
+    # the product's host transcript and the oracle (CPU baseline) each get their own copy: neither includes the other's tree
+    for path in (os.path.join(os.path.dirname(__file__), "..", "zk-circuits_amd", "csrc", "poseidon_fast_constants.h"),
+                 os.path.join(os.path.dirname(__file__), "..", "oracle", "poseidon_fast_constants.h")):
+      with open(path, "w") as f:
+          f.write("// GENERATED by tools/gen_poseidon_fast.py (derivation and self-check there); do not edit.\n")
+          f.write("// Fast form of the 22 partial rounds: s += FIRST; s[1:] = INIT*s[1:]; per round s0 = sbox(s0) + Q[t];\n")
+          f.write("// (s0, rest) = (25*s0 + WHAT[t].rest, rest + s0*V[t]).\n#pragma once\n")
+          f.write("#define QP_POSEIDON_FAST_FIRST " + arr(first) + "\n")
+          f.write("#define QP_POSEIDON_FAST_Q " + arr(Q) + "\n")
+          f.write("#define QP_POSEIDON_FAST_INIT \\\n" + ", \\\n".join("  {" + arr(row) + "}" for row in init) + "\n")
+          f.write("#define QP_POSEIDON_FAST_WHAT \\\n" + ", \\\n".join("  {" + arr(S[t][1]) + "}" for t in range(22)) + "\n")
+          f.write("#define QP_POSEIDON_FAST_V \\\n" + ", \\\n".join("  {" + arr(S[t][2]) + "}" for t in range(22)) + "\n")
+      print("wrote", path)
