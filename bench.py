@@ -144,6 +144,12 @@ def main():
         if n_l.value:
             all_groups[L.qpgpu_profile_name(kid).decode()] = {"launches": n_l.value, "avg_ms": ms.value / n_l.value, "total_ms": ms.value,
                                                             "alg_bytes_per_launch": by.value / n_l.value}
+    if dist is not None:
+        # the first collective on a communicator connects the ranks and allocates its buffers (tens of ms): do one gather of the
+        # same shape before the timed region, as a long-running aggregator would have
+        warm = torch.zeros(gc.proof_size * args.steps * args.batch, dtype=torch.uint8, device=dev)
+        dist.all_gather([torch.empty_like(warm) for _ in range(world)], warm)
+        del warm
     L.qpgpu_profile_reset()
     L.qpgpu_profile_enable(1)
     barrier()
