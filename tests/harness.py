@@ -105,9 +105,12 @@ class SynthCircuit:
             raise ValueError(S.qpsynth_last_error().decode())
         for k, v in overrides.items():
             if k == "fri_arity_bits":
-                for i, a in enumerate(v):
-                    self.params.fri_arity_bits[i] = a
+                for i in range(8):
+                    self.params.fri_arity_bits[i] = v[i] if i < len(v) else 0
                 self.params.fri_num_layers = len(v)
+            elif k == "n_recursion":
+                for i, a in enumerate(v):
+                    self.params.n_recursion[i] = a
             else:
                 setattr(self.params, k, v)
         h = ctypes.c_void_p()

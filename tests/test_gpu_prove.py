@@ -199,3 +199,42 @@ def test_split_quotient_is_not_used_for_recursion_gates(monkeypatch):
         assert first_diff(gc.prove(w, p), oc.prove(w, p)) is None
     finally:
         gc.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_gate_mixes_match_oracle(seed):
+    """Randomised circuit packages: degree, zk, gate-row mix (leaf and recursion kinds, either parameter set), copy count,
+    FRI schedule — GPU bytes == oracle bytes, and the oracle verifier accepts."""
+    import random
+    rnd = random.Random(1000 + seed)
+    k = rnd.choice([7, 8, 9, 10])
+    n = 1 << k
+    zk = rnd.random() < 0.4
+    rec = rnd.random() < 0.6
+    budget = n - 3 - (n // 8 if zk else 0)                       # leave Noop rows (zk blinding wants some)
+    parts = [rnd.random() for _ in range(4 + (8 if rec else 0))]
+    tot = sum(parts)
+    rows = [max(1, int(budget * 0.8 * p / tot)) for p in parts]
+    ov = dict(degree_bits=k, zero_knowledge=int(zk), n_poseidon=rows[0], n_basesum=rows[1], n_arith=rows[2], n_constant=rows[3],
+              n_copies=rnd.randrange(0, 4 * n), circuit_seed=0x1234 + seed, reserved=(rnd.randrange(2) if rec else 0))
+    arities = []
+    left = k - 1                                                 # every FRI layer tree must keep at least cap-many (16) leaves
+    while left > 0 and len(arities) < 3 and rnd.random() < 0.8:
+        a = rnd.randint(1, min(4, left)); arities.append(a); left -= a
+    ov["fri_arity_bits"] = arities
+    sc = SynthCircuit("T", **ov)
+    if rec:
+        for i in range(8):
+            sc.params.n_recursion[i] = rows[4 + i]
+        sc = SynthCircuit(None, **{f: getattr(sc.params, f) for f in ("degree_bits", "zero_knowledge", "n_poseidon", "n_basesum", "n_arith",
+                                                                        "n_constant", "n_copies", "circuit_seed", "reserved")},
+                          fri_arity_bits=arities, n_recursion=list(sc.params.n_recursion))
+    oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+    try:
+        w, p = sc.witness(seed)
+        salts = sc.salts(seed) if zk else None
+        want = oc.prove(w, p, salts)
+        got = gc.prove(w, p, salt_seed=seed)
+        assert first_diff(got, want) is None and oc.verify(got) is None
+    finally:
+        gc.close()
