@@ -27,3 +27,72 @@ def test_gloo_world2_gather_of_proof_blobs(tmp_path):
                         "--master-port", "29611", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def _fake_chunk_prover_src():
+    return textwrap.dedent("""
+        import hashlib
+        def chunk_prover(chunk, level):
+            # stand-in for aggregate_chunk: a fixed-size blob that depends on the children, their order and the level
+            h = hashlib.sha256(bytes([level]) + b"|".join(chunk)).digest()
+            return agg.AggregatedProof(h * 4)                      # 128-byte "proof"
+        def size_of(level):
+            return 200 if level == 0 else 128
+    """)
+
+
+def test_tree_orchestration_single_process():
+    import importlib, hashlib
+    agg = importlib.import_module("zk-circuits_amd.aggregator")
+    ns = {"agg": agg}
+    exec(_fake_chunk_prover_src(), ns)
+    for b, depth in ((2, 3), (4, 2), (3, 2)):
+        cfg = agg.TreeAggregationConfig(b, depth)
+        leaves = [bytes([i]) * 200 for i in range(cfg.num_leaf_proofs)]
+        calls = []
+        def prover(chunk, level):
+            calls.append((level, len(chunk))); return ns["chunk_prover"](chunk, level)
+        root = agg.aggregate_to_tree(leaves, cfg, prover)
+        # reference semantics (tree.rs:56-103): consecutive chunks of b, level by level
+        cur, lvl = leaves, 0
+        while len(cur) > 1 or lvl == 0:
+            cur = [ns["chunk_prover"](cur[i:i + b], lvl).proof for i in range(0, len(cur), b)]; lvl += 1
+        assert root.proof == cur[0] and lvl == depth
+        assert [c for c in calls if c[0] == 0] == [(0, b)] * (cfg.num_leaf_proofs // b)
+    # the aggregator pads with the dummy proof and then runs the same tree (aggregator.rs:74-92)
+    cfg = agg.TreeAggregationConfig(2, 2)
+    a = agg.WormholeProofAggregator(None, cfg)
+    for i in range(3):
+        a.push_proof(bytes([i]) * 200)
+    dummy = bytes([9]) * 200
+    root = a.aggregate(dummy_proof=dummy, chunk_prover=ns["chunk_prover"])
+    want = agg.aggregate_to_tree([bytes([0]) * 200, bytes([1]) * 200, bytes([2]) * 200, dummy], cfg, ns["chunk_prover"])
+    assert root.proof == want.proof
+
+
+def test_gloo_world2_distributed_tree_matches_single_process(tmp_path):
+    script = tmp_path / "t.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        agg = importlib.import_module("zk-circuits_amd.aggregator")
+    """ % ROOT) + _fake_chunk_prover_src() + textwrap.dedent("""
+        for b, depth in ((2, 3), (2, 5), (4, 2), (2, 1)):
+            cfg = agg.TreeAggregationConfig(b, depth)
+            n = cfg.num_leaf_proofs
+            leaves = [bytes([i % 251]) * 200 for i in range(n)]
+            per = n // world
+            root = agg.aggregate_to_tree_distributed(leaves[rank * per:(rank + 1) * per], cfg, chunk_prover, size_of)
+            want = agg.aggregate_to_tree(leaves, cfg, chunk_prover)
+            assert root.proof == want.proof, (b, depth, rank)
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29612", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

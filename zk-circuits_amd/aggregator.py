@@ -68,7 +68,9 @@ class WormholeProofAggregator:
         for i in range(b):
             self.push_proof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs))
 
-    def aggregate(self, dummy_proof=None):
+    def aggregate(self, dummy_proof=None, chunk_prover=None):
+        """aggregator.rs:74-92. With a `chunk_prover` (see aggregate_to_tree) the padded leaves are aggregated to the root proof;
+        without one the padded leaf set is returned (what aggregate_level consumes)."""
         if self.proofs_buffer is None:
             raise RuntimeError("there are no proofs to aggregate")
         proofs, self.proofs_buffer = self.proofs_buffer, None
@@ -81,6 +83,8 @@ class WormholeProofAggregator:
                     raise RuntimeError("failed to deserialize dummy proof")
                 dummy_proof = proofs[0]
             proofs = proofs + [dummy_proof] * (self.config.num_leaf_proofs - num_real)
+        if chunk_prover is not None:
+            return aggregate_to_tree(proofs, self.config, chunk_prover)
         return AggregatedLeaves(proofs, num_real)
 
 
@@ -102,3 +106,71 @@ def gather_proofs(local_proofs, proof_size, group=None, device=None):
         raw = o.cpu().numpy().tobytes()
         res += [raw[i * proof_size:(i + 1) * proof_size] for i in range(k)]
     return res
+
+
+# ------------------------------------------------------------------------------------------------ tree orchestration
+# Mirror of aggregate_to_tree / aggregate_level / aggregate_chunk (tree.rs:56-143). What a chunk prover does in the reference —
+# build the recursive-verifier circuit for the children's common data, set the proof targets, prove — is split at the C-ABI:
+# circuit building and witness generation are qp-plonky2 host code (Rust), `circuit_data.prove(pw)` is qpgpu_prove on the
+# recursion circuit. Here the chunk prover is a callable, so the control flow (levels, chunking, order, which rank proves which
+# node, the exchange of fixed-size blobs) is the reference's, whatever produces the parent proof.
+
+class AggregatedProof:
+    """tree.rs:24-28: the proof plus the circuit data needed to verify it / to aggregate it further."""
+
+    def __init__(self, proof, circuit_data=None):
+        self.proof = proof
+        self.circuit_data = circuit_data
+
+
+def aggregate_level(proofs, chunk_prover, config, level):
+    """tree.rs:92-103: consecutive chunks of `tree_branching_factor` children, one parent each, order preserved. `chunk_prover(chunk,
+    level)` returns an AggregatedProof; the reference maps it with par_chunks — a prover may batch its chunks on the device instead."""
+    b = config.tree_branching_factor
+    return [chunk_prover(proofs[i:i + b], level) for i in range(0, len(proofs), b)]
+
+
+def aggregate_to_tree(leaf_proofs, config, chunk_prover):
+    """tree.rs:56-79: aggregate level by level until one proof is left."""
+    proofs = aggregate_level(list(leaf_proofs), chunk_prover, config, 0)
+    level = 1
+    while len(proofs) > 1:
+        proofs = aggregate_level([p.proof for p in proofs], chunk_prover, config, level)
+        level += 1
+    assert len(proofs) == 1
+    return proofs[0]
+
+
+def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof_size_of_level, group=None, device=None):
+    """The same tree over torch.distributed ranks: rank r holds a contiguous, equally sized run of the leaves.
+    While a rank's run holds whole chunks, a level is local work with no communication. Once it does not, the level's proofs
+    (fixed-size blobs) are all-gathered in rank order and the chunks are dealt out to ranks 0..chunks-1; every rank returns the root.
+    `proof_size_of_level(level)` is the byte size of the proofs that ENTER that level (level 0: leaf proofs). One collective per
+    level at the top of the tree, none below: RCCL (backend "nccl") on GPU tensors, gloo on CPU tensors."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = config.tree_branching_factor
+    proofs, level, spread = list(local_leaf_proofs), 0, True          # spread: every rank still holds its own run
+    total = len(proofs) * world
+    while total > 1:
+        if spread and len(proofs) % b == 0 and len(proofs) >= b:
+            proofs = [p.proof for p in aggregate_level(proofs, chunk_prover, config, level)]
+        else:
+            if spread:
+                everything = gather_proofs(proofs, proof_size_of_level(level), group=group, device=device)
+                spread = False
+            else:
+                everything = proofs                                     # already replicated on every rank
+            chunks = [everything[i:i + b] for i in range(0, len(everything), b)]
+            mine = [chunk_prover(c, level).proof for i, c in enumerate(chunks) if i % world == rank]
+            # one parent per chunk; parents are gathered back in chunk order (rank i % world proved chunk i)
+            per_rank = (len(chunks) + world - 1) // world
+            size = proof_size_of_level(level + 1)
+            padded = mine + [bytes(size)] * (per_rank - len(mine))
+            gathered = gather_proofs(padded, size, group=group, device=device)
+            proofs = [gathered[(i % world) * per_rank + i // world] for i in range(len(chunks))]
+        total = (total + b - 1) // b
+        level += 1
+    if spread:                                                          # a single rank with a single leaf run
+        proofs = gather_proofs(proofs, proof_size_of_level(level), group=group, device=device)[:1]
+    return AggregatedProof(proofs[0])
