@@ -56,6 +56,44 @@ def test_aggregator_leaf_batch_and_padding(pkg):                 # aggregator_te
         assert res.public_inputs[16 * i:16 * (i + 1)] == [int(x) for x in p]
 
 
+def test_aggregation_tree_with_device_chunk_prover(pkg):          # tree.rs:56-143 control flow, qpgpu_prove per chunk
+    """aggregate() to a root through the device: leaves proved as a batch, every tree node proved with qpgpu_prove on a
+    recursion-shaped circuit (all 14 gate types). The witness of a node comes from a STAND-IN generator seeded by its children's
+    bytes (the real one is qp-plonky2's recursive-verifier CircuitBuilder on the Rust host), so the root proves nothing about the
+    leaves; what is checked is the orchestration: level/chunk order, one circuit handle per level, every node proof accepted by the
+    oracle verifier for its circuit and byte-equal to the oracle's proof of the same witness, and determinism of the root."""
+    import hashlib
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.test_config())
+    cfg = pkg.TreeAggregationConfig(2, 2)
+    level_circuits = {}                                          # per-level cache (the reference rebuilds per chunk, tree.rs:127)
+    seen = []
+
+    def chunk_prover(chunk, level):
+        if level not in level_circuits:
+            sc = SynthCircuit("RT", circuit_seed=0x7EE0 + level)
+            level_circuits[level] = (sc, GpuCircuit(sc.desc), OracleCircuit(sc.desc))
+        sc, gc, oc = level_circuits[level]
+        seed = int.from_bytes(hashlib.sha256(b"".join(bytes(c) if not hasattr(c, "to_bytes") else c.to_bytes() for c in chunk)).digest()[:7], "little")
+        w, p = sc.witness(seed)
+        proof = gc.prove(w, p)
+        assert oc.verify(proof) is None and proof == oc.prove(w, p)
+        seen.append((level, len(chunk)))
+        return pkg.aggregator.AggregatedProof(proof, sc)
+
+    def run():
+        agg = pkg.WormholeProofAggregator(cd, cfg)
+        agg.prove_leaves([pkg.CircuitInputs.test_inputs(i) for i in range(3)])      # 3 real leaves + 1 dummy
+        return agg.aggregate(chunk_prover=chunk_prover)
+
+    try:
+        root = run()
+        assert seen == [(0, 2), (0, 2), (1, 2)] and len(level_circuits) == 2
+        assert run().proof == root.proof
+    finally:
+        for _, gc, _ in level_circuits.values():
+            gc.close()
+
+
 def test_large_merkle_tree_fused_levels():
     rng = np.random.default_rng(77)
     width, leaves, cap = 9, 1 << 20, 4                           # >= 2^20 leaves takes the fused level-1/2 path

@@ -11,4 +11,5 @@ The product path never touches oracle/ and has no CPU fallback: loading fails lo
 from .ffi import lib, QpgpuError, CircuitDesc, ProveOpts, Gate  # noqa: F401
 from .prover import (CircuitConfig, CircuitInputs, ProofWithPublicInputs, WormholeProver,  # noqa: F401
                      WormholeCircuitData)
-from .aggregator import WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves  # noqa: F401
+from .aggregator import (WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves, AggregatedProof,  # noqa: F401
+                         aggregate_to_tree, aggregate_level, aggregate_to_tree_distributed, gather_proofs)
