@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra (untimed-headline) stream-pipelined throughput measurement")
     ap.add_argument("--cpu-proofs", type=int, default=8)
+    ap.add_argument("--no-tree", action="store_true", help="skip the extra aggregation-tree measurement (BASELINE configs[2]/[3] flavour)")
     args = ap.parse_args()
 
     import numpy as np
@@ -80,6 +81,10 @@ def main():
         if rank == 0:
             print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     dist = None
+    # stdout carries exactly one JSON line: libraries that print banners there (RCCL prints its version block at communicator
+    # creation) are pointed at stderr, and the line goes to the saved descriptor at the end
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world > 1 or os.environ.get("QP_BENCH_FORCE_DIST"):      # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -213,6 +218,60 @@ def main():
         pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
                      "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
 
+    # ---- extra, NOT the headline: an aggregation tree over 64 leaves per GPU (BASELINE configs[2]/[3] flavour).
+    # Leaves: one qpgpu_prove_batch of this preset. Nodes: level by level (tree.rs:56-103), every level one device batch of proofs of
+    # a recursion-shaped circuit (all 14 gate types, 2^13 rows). The node witnesses come from a small pre-generated pool picked by a hash
+    # of the children — a STAND-IN for qp-plonky2's recursive-verifier witness generator (Rust host code): the timing is that of
+    # the device work of aggregate(), the root proves nothing about the leaves. With N > 1 ranks the top levels exchange fixed-size
+    # proof blobs over RCCL (aggregate_to_tree_distributed).
+    tree = None
+    if args.batch == 1 and not args.no_tree and args.preset in ("A", "B"):
+        try:
+            import hashlib, importlib
+            agg = importlib.import_module("zk-circuits_amd.aggregator")
+            leaves_per_rank = 64
+            scR = H.SynthCircuit("R"); gcR = H.GpuCircuit(scR.desc, device=local_rank)
+            pool = []
+            for i in range(4):
+                w, p = scR.witness(7000 + rank * 16 + i)
+                pool.append((torch.from_numpy(w.view(np.int64)).to(dev), p))
+
+            class NodeProver:
+                def pick(self, chunk):
+                    return pool[hashlib.sha256(chunk[0][:64] + chunk[-1][-64:]).digest()[0] % len(pool)]
+                def prove_chunks(self, chunks, level):
+                    sel = [self.pick(c) for c in chunks]
+                    out = gcR.prove_batch([s[0].data_ptr() for s in sel], [s[1] for s in sel], salt_seed=level, wires_on_device=True)
+                    return [agg.AggregatedProof(o) for o in out]
+                def __call__(self, chunk, level):
+                    return self.prove_chunks([chunk], level)[0]
+            depth = int(round(np.log2(leaves_per_rank * world)))
+            cfg = agg.TreeAggregationConfig(2, depth)
+            ptrs = [wit_dev[j % nwit].data_ptr() for j in range(leaves_per_rank)]
+            pl = [pis_list[j % nwit] for j in range(leaves_per_rank)]
+            np_ = NodeProver()
+            np_.prove_chunks([[b"\0" * 64, b"\0" * 64]] * 4, 0)               # warm the node circuit's workspaces
+            barrier(); t3 = time.perf_counter()
+            leaf_proofs = gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)
+            barrier(); t4 = time.perf_counter()
+            if dist is not None:
+                root = agg.aggregate_to_tree_distributed(leaf_proofs, cfg, np_, lambda lvl: gc.proof_size if lvl == 0 else gcR.proof_size, device=dev)
+            else:
+                root = agg.aggregate_to_tree(leaf_proofs, cfg, np_)
+            barrier(); t5 = time.perf_counter()
+            tl, tt = t4 - t3, t5 - t4
+            if dist is not None:
+                t = torch.tensor([tl, tt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); tl, tt = float(t[0]), float(t[1])
+            n_leaves = leaves_per_rank * world
+            tree = {"leaves": n_leaves, "branching": 2, "levels": depth, "nodes": n_leaves - 1,
+                    "leaf_stage_s": round(tl, 4), "leaf_proofs_per_s": round(n_leaves / tl, 1),
+                    "tree_stage_s": round(tt, 4), "total_s": round(tl + tt, 4), "root_bytes": len(root.proof),
+                    "note": "node witnesses from a pre-generated pool (stand-in for the Rust recursive-verifier witness generator); "
+                            "device work of aggregate() only"}
+            gcR.close()
+        except Exception as e:                                  # never let the extra measurement take the headline down
+            tree = {"error": repr(e)[:200]}
+
     # Poseidon throughput of the dominant kernel against the measured VALU issue ceiling
     valu = None
     if "merkle_leaves_colmajor" in kernels:
@@ -249,7 +308,7 @@ def main():
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "host_cpus": pinned, "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
-        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "aggregation_tree": tree, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample
@@ -272,7 +331,7 @@ def main():
                                "ms_per_proof": round(cdt / args.cpu_proofs * 1e3, 2)}
         out["bit_exact_vs_cpu"] = bool(cpu_pf == gc.prove(None, p0, salt_seed=seeds[0], wires_dev_ptr=wit_dev[0].data_ptr()))
     if rank == 0:
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n"); json_out.flush()
     gc.close()
     if dist is not None:
         dist.destroy_process_group()

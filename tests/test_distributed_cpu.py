@@ -59,6 +59,18 @@ def test_tree_orchestration_single_process():
             cur = [ns["chunk_prover"](cur[i:i + b], lvl).proof for i in range(0, len(cur), b)]; lvl += 1
         assert root.proof == cur[0] and lvl == depth
         assert [c for c in calls if c[0] == 0] == [(0, b)] * (cfg.num_leaf_proofs // b)
+    # a prover object may take a whole level as one batch (prove_chunks): same root
+    class Batched:
+        levels = []
+        def prove_chunks(self, chunks, level):
+            self.levels.append((level, len(chunks))); return [ns["chunk_prover"](c, level) for c in chunks]
+        def __call__(self, chunk, level):
+            return ns["chunk_prover"](chunk, level)
+    cfg = agg.TreeAggregationConfig(2, 3)
+    leaves = [bytes([i]) * 200 for i in range(8)]
+    bp = Batched()
+    assert agg.aggregate_to_tree(leaves, cfg, bp).proof == agg.aggregate_to_tree(leaves, cfg, ns["chunk_prover"]).proof
+    assert bp.levels == [(0, 4), (1, 2), (2, 1)]
     # the aggregator pads with the dummy proof and then runs the same tree (aggregator.rs:74-92)
     cfg = agg.TreeAggregationConfig(2, 2)
     a = agg.WormholeProofAggregator(None, cfg)

@@ -127,7 +127,10 @@ def aggregate_level(proofs, chunk_prover, config, level):
     """tree.rs:92-103: consecutive chunks of `tree_branching_factor` children, one parent each, order preserved. `chunk_prover(chunk,
     level)` returns an AggregatedProof; the reference maps it with par_chunks — a prover may batch its chunks on the device instead."""
     b = config.tree_branching_factor
-    return [chunk_prover(proofs[i:i + b], level) for i in range(0, len(proofs), b)]
+    chunks = [proofs[i:i + b] for i in range(0, len(proofs), b)]
+    if hasattr(chunk_prover, "prove_chunks"):                     # a device prover takes the whole level as one batch (par_chunks analogue)
+        return chunk_prover.prove_chunks(chunks, level)
+    return [chunk_prover(c, level) for c in chunks]
 
 
 def aggregate_to_tree(leaf_proofs, config, chunk_prover):
