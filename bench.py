@@ -230,11 +230,18 @@ def main():
             import hashlib, importlib
             agg = importlib.import_module("zk-circuits_amd.aggregator")
             leaves_per_rank = 64
-            scR = H.SynthCircuit("R"); gcR = H.GpuCircuit(scR.desc, device=local_rank)
-            pool = []
-            for i in range(4):
-                w, p = scR.witness(7000 + rank * 16 + i)
-                pool.append((torch.from_numpy(w.view(np.int64)).to(dev), p))
+            setup_ok, pool, gcR = 1, [], None
+            try:
+                scR = H.SynthCircuit("R"); gcR = H.GpuCircuit(scR.desc, device=local_rank)
+                for i in range(4):
+                    w, p = scR.witness(7000 + rank * 16 + i)
+                    pool.append((torch.from_numpy(w.view(np.int64)).to(dev), p))
+            except Exception:
+                setup_ok = 0
+            if dist is not None:                                  # all ranks enter the collectives below, or none does
+                t = torch.tensor([setup_ok], dtype=torch.int32, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); setup_ok = int(t.item())
+            if not setup_ok:
+                raise RuntimeError("aggregation-tree setup failed on a rank")
 
             class NodeProver:
                 def pick(self, chunk):
