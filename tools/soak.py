@@ -10,14 +10,14 @@ for preset in ("B", "A", "RT"):
     wit = [sc.witness(900 + i) for i in range(4)]
     dev = [torch.from_numpy(w.view(np.int64)).cuda() for w, _ in wit]
     ref = [gc.prove(None, wit[i][1], salt_seed=5 + i, wires_dev_ptr=dev[i].data_ptr()) for i in range(4)]
-    n_single = 1500 if preset != "RT" else 3000
+    n_single = int(os.environ.get("SOAK_N", "1500")) * (1 if preset != "RT" else 2)
     t = time.perf_counter()
     for k in range(n_single):
         i = k % 4
         assert gc.prove(None, wit[i][1], salt_seed=5 + i, wires_dev_ptr=dev[i].data_ptr()) == ref[i], ("single", preset, k)
     bad = []
     def worker(tid):
-        for k in range(300):
+        for k in range(int(os.environ.get("SOAK_T", "300"))):
             i = (k + tid) % 4
             if gc.prove(None, wit[i][1], salt_seed=5 + i, wires_dev_ptr=dev[i].data_ptr()) != ref[i]:
                 bad.append((tid, k)); return
@@ -29,5 +29,5 @@ for preset in ("B", "A", "RT"):
         # batch proof j uses salt_seed + j: compare against fresh single proofs with the same seed for a few of them
         for j in (0, 7, 31):
             assert out[j] == gc.prove(None, wit[j % 4][1], salt_seed=5 + j, wires_dev_ptr=dev[j % 4].data_ptr()), ("batch", preset, rep, j)
-    print(preset, "ok: %d single + 1200 threaded + 320 batched proofs, %.1f s" % (n_single, time.perf_counter() - t), flush=True)
+    print(preset, "ok: %d single + %d threaded + 320 batched proofs, %.1f s" % (n_single, 4 * int(os.environ.get("SOAK_T", "300")), time.perf_counter() - t), flush=True)
     gc.close()
