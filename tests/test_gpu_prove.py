@@ -238,3 +238,19 @@ def test_random_gate_mixes_match_oracle(seed):
         assert first_diff(got, want) is None and oc.verify(got) is None
     finally:
         gc.close()
+
+
+def test_gpu_proofs_match_the_committed_self_check_digests():
+    """The same regression digests as tests/test_oracle_prover.py, straight from the device path (no oracle call)."""
+    import hashlib, json, os
+    chk = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfcheck.json")))
+    for key, want in sorted(chk.items()):
+        preset, seed = key.split("/"); seed = int(seed)
+        sc = SynthCircuit(preset); gc = GpuCircuit(sc.desc)
+        try:
+            w, p = sc.witness(seed)
+            pf = gc.prove(w, p, salt_seed=seed)
+            assert len(pf) == want["len"] and hashlib.sha256(pf).hexdigest() == want["sha256"], key
+            assert hashlib.sha256(gc.cap().tobytes()).hexdigest() == want["cap_sha256"], key
+        finally:
+            gc.close()

@@ -155,3 +155,21 @@ def test_recursion_gate_violation_gives_rejected_proof(rec_tiny):
     w, p = sc.witness(5)
     w[9, rec_first_row(sc, 7)] = (int(w[9, rec_first_row(sc, 7)]) + 1) % P      # a CosetInterpolation value wire
     assert oc.verify(oc.prove(w, p)) is not None
+
+
+def _selfcheck():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfcheck.json")))
+
+
+@pytest.mark.parametrize("key", sorted(k for k in _selfcheck() if not k.startswith("A/")))
+def test_oracle_proofs_match_the_committed_self_check_digests(key):
+    """Regression fixture of this repo's own restatement (tests/golden/make_selfcheck.py) — not a reference output."""
+    import hashlib
+    preset, seed = key.split("/"); seed = int(seed)
+    sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc)
+    w, p = sc.witness(seed)
+    pf = oc.prove(w, p, sc.salts(seed) if sc.desc.zero_knowledge else None)
+    want = _selfcheck()[key]
+    assert len(pf) == want["len"] and hashlib.sha256(pf).hexdigest() == want["sha256"]
+    assert hashlib.sha256(oc.cap().tobytes()).hexdigest() == want["cap_sha256"]
