@@ -346,12 +346,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int nc = (int)g.param, start_accs = 6 + (xc ? 2 : 1) * nc;
         const Ext alpha = ex(Wv(2), Wv(3));
         Ext acc = ex(Wv(4), Wv(5));
-        for (int i = 0; i < nc; i++) {
-          const Ext coeff = xc ? ex(Wv(6 + 2 * i), Wv(7 + 2 * i)) : ex(Wv(6 + i), 0);
-          const Ext acc_i = i == nc - 1 ? ex(Wv(0), Wv(1)) : ex(Wv(start_accs + 2 * i), Wv(start_accs + 2 * i + 1));
-          const Ext t = ex_sub(ex_add(ex_mul(acc, alpha), coeff), acc_i);
-          ACC_TERM(t.a, 2 * i); ACC_TERM(t.b, 2 * i + 1);
-          acc = acc_i;
+        for (int i0 = 0; i0 < nc; i0 += 4) {                    // four steps' loads (up to 16) issued together
+          u64 ca[4], cb[4], aa[4], ab[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u; const bool ok = i < nc;
+            ca[u] = ok ? (xc ? Wv(6 + 2 * i) : Wv(6 + i)) : 0; cb[u] = (ok && xc) ? Wv(7 + 2 * i) : 0;
+            const int ai = i == nc - 1 ? 0 : start_accs + 2 * i;
+            aa[u] = ok ? Wv(ai) : 0; ab[u] = ok ? Wv(ai + 1) : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            if (i >= nc) continue;
+            const Ext acc_i = ex(aa[u], ab[u]);
+            const Ext t = ex_sub(ex_add(ex_mul(acc, alpha), ex(ca[u], cb[u])), acc_i);
+            ACC_TERM(t.a, 2 * i); ACC_TERM(t.b, 2 * i + 1);
+            acc = acc_i;
+          }
         }
         break;
       }
@@ -399,10 +411,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int nb = (int)g.param;
         const u64 base = Wv(0);
         u64 prev = 1;
-        for (int i = 0; i < nb; i++) {
-          const u64 bit = Wv(1 + (nb - 1 - i)), inter = Wv(2 + nb + i);
-          ACC_TERM(gl_sub(gl_mul(prev, gl_add(gl_mul(bit, base), gl_sub(1, bit))), inter), i);
-          prev = gl_sqr(inter);
+        for (int i0 = 0; i0 < nb; i0 += 8) {                    // eight steps' loads issued together
+          u64 bv[8], iv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int i = i0 + u; bv[u] = i < nb ? Wv(1 + (nb - 1 - i)) : 0; iv[u] = i < nb ? Wv(2 + nb + i) : 0; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int i = i0 + u;
+            if (i >= nb) continue;
+            ACC_TERM(gl_sub(gl_mul(prev, gl_add(gl_mul(bv[u], base), gl_sub(1, bv[u]))), iv[u]), i);
+            prev = gl_sqr(iv[u]);
+          }
         }
         ACC_TERM(gl_sub(Wv(1 + nb), Wv(2 + nb + nb - 1)), nb);
         break;
