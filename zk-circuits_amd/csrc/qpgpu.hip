@@ -256,13 +256,21 @@ static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, in
   bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
 }
 
+// No C++ exception may cross the C ABI (include/qpgpu.h): host allocation failures and the like become status codes.
+template <class F> static int abi_guard(F&& f) {
+  try { return f(); }
+  catch (const std::bad_alloc&) { return set_err(QPGPU_ERR_OOM, "host memory allocation failed"); }
+  catch (const std::exception& e) { return set_err(QPGPU_ERR_HIP, std::string("internal error: ") + e.what()); }
+  catch (...) { return set_err(QPGPU_ERR_HIP, "internal error"); }
+}
+
 // ------------------------------------------------------------------------------------------------ API
 extern "C" {
 
 const char* qpgpu_last_error(void) { return g_last_error.c_str(); }
 int qpgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
-int qpgpu_ctx_create(int device, qpgpu_ctx** out) {
+int qpgpu_ctx_create(int device, qpgpu_ctx** out) { return abi_guard([&]() -> int {
   if (!out) return set_err(QPGPU_ERR_ARG, "null out");
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return set_err(QPGPU_ERR_NO_DEVICE, "no HIP device visible");
@@ -274,7 +282,7 @@ int qpgpu_ctx_create(int device, qpgpu_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   *out = new qpgpu_ctx{device};
   return 0;
-}
+}); }
 void qpgpu_ctx_destroy(qpgpu_ctx* ctx) { delete ctx; }
 
 void qpgpu_circuit_destroy(qpgpu_circuit* c) {
@@ -286,7 +294,7 @@ void qpgpu_circuit_destroy(qpgpu_circuit* c) {
   delete c;
 }
 
-int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_circuit** out) {
+int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_circuit** out) { return abi_guard([&]() -> int {
   if (!ctx || !desc || !out) return set_err(QPGPU_ERR_ARG, "null argument");
   const qpgpu_circuit_desc& d = *desc;
   if (d.degree_bits < 2 || d.degree_bits + d.fri_rate_bits > 28) return set_err(QPGPU_ERR_ARG, "degree_bits out of range");
@@ -421,7 +429,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   c->split_quotient = quotient_split_supported(c->cd) && c->leaf_gates_only;
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
   *out = c; return 0;
-}
+}); }
 
 // ---- CommonCircuitData / VerifierOnlyCircuitData parsers (byte layouts: SURVEY.md App. B.1-B.2)
 namespace {
@@ -442,7 +450,7 @@ bool read_fri_config(ByteReader& r, uint32_t out[4]) {
 }
 }
 int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* d, qpgpu_gate* gates, size_t gates_cap,
-                       uint32_t* selector_indices, uint32_t* selector_group_ranges, size_t groups_cap, uint64_t* k_is, size_t k_is_cap) {
+                       uint32_t* selector_indices, uint32_t* selector_group_ranges, size_t groups_cap, uint64_t* k_is, size_t k_is_cap) { return abi_guard([&]() -> int {
   if (!bytes || !d || !gates || !selector_indices || !selector_group_ranges || !k_is) return set_err(QPGPU_ERR_ARG, "null argument");
   ByteReader r{bytes, len};
   memset(d, 0, sizeof *d);
@@ -493,8 +501,8 @@ int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* d, 
   if (r.pos != len) return set_err(QPGPU_ERR_ARG, "trailing bytes after common data");
   d->gates = gates; d->selector_indices = selector_indices; d->selector_group_ranges = selector_group_ranges; d->k_is = k_is;
   return 0;
-}
-int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_out, size_t cap_words, uint64_t digest_out[4]) {
+}); }
+int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_out, size_t cap_words, uint64_t digest_out[4]) { return abi_guard([&]() -> int {
   if (!bytes || !cap_out || !digest_out) return set_err(QPGPU_ERR_ARG, "null argument");
   ByteReader r{bytes, len};
   uint64_t ch = r.u64_(); if (!r.ok || ch > 20) return set_err(QPGPU_ERR_ARG, "bad cap height");
@@ -503,7 +511,7 @@ int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_ou
   for (int i = 0; i < 4; i++) digest_out[i] = r.u64_();
   if (!r.ok) return set_err(QPGPU_ERR_ARG, "verifier data truncated");
   return (int)ch;
-}
+}); }
 
 int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit* c, uint64_t* out_cap) {
   if (!c || !out_cap) return set_err(QPGPU_ERR_ARG, "null argument");
@@ -727,7 +735,7 @@ int qpgpu_profile_get(int id, uint64_t* launches, double* ms, double* alg_bytes)
 }
 
 int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
-                const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len) {
+                const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len) { return abi_guard([&]() -> int {
   if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");
   if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
   if (out_cap < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "output buffer too small: need " + std::to_string(c->lay.total));
@@ -739,17 +747,17 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
   ws_release(c, w);
   if (rc == 0 && out_len) *out_len = c->lay.total;
   return rc;
-}
+}); }
 
 int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wires, const uint64_t* const* public_inputs,
-                      size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride, size_t* out_lens) {
+                      size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride, size_t* out_lens) { return abi_guard([&]() -> int {
   if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");
   if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
   if (out_stride < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "out_stride smaller than proof size");
   if (batch == 0) return 0;
   int workers = getenv_int("QPGPU_STREAMS", 4); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
   std::atomic<size_t> next(0); std::atomic<int> first_rc(0); std::mutex emu; std::string emsg;
-  auto body = [&]() {
+  auto body_inner = [&]() {
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
@@ -767,12 +775,16 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
     w->shared_gpu = false; w->batch_mode = false;
     ws_release(c, w);
   };
+  auto body = [&]() {
+    try { body_inner(); }
+    catch (...) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = QPGPU_ERR_OOM; emsg = "internal error in a batch worker (host allocation?)"; } }
+  };
   std::vector<std::thread> th;
-  for (int t = 1; t < workers; t++) th.emplace_back(body);
+  for (int t = 1; t < workers; t++) { try { th.emplace_back(body); } catch (...) { break; } }     // fewer workers if threads cannot be created
   body();
   for (auto& t : th) t.join();
   if (first_rc.load()) return set_err(first_rc.load(), emsg);
   return 0;
-}
+}); }
 
 } // extern "C"
