@@ -1,322 +1,23 @@
-"""Shared test/bench harness: ctypes bindings for the oracle (checker), the synthetic generator and the product C-ABI.
+"""Shared test harness: the product binding (zk-circuits_amd/ffi.py: C-ABI + synthetic generator) re-exported next to the oracle
+binding (oracle/binding.py, the checker) plus a few test helpers.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/ (it is the checker).
 """
-import ctypes, os, subprocess, sys
+import ctypes, importlib, os, subprocess, sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "zk-circuits_amd")
-P = 0xFFFFFFFF00000001
-u64p = ctypes.POINTER(ctypes.c_uint64)
-u32p = ctypes.POINTER(ctypes.c_uint32)
-u8p = ctypes.POINTER(ctypes.c_uint8)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+_ffi = importlib.import_module("zk-circuits_amd.ffi")
+from oracle.binding import oracle, OracleCircuit          # noqa: E402,F401
 
-
-class Gate(ctypes.Structure):
-    _fields_ = [("tag", ctypes.c_uint32), ("param2", ctypes.c_uint32), ("param", ctypes.c_uint64), ("param3", ctypes.c_uint32),
-                ("table_len", ctypes.c_uint32), ("table", ctypes.POINTER(ctypes.c_uint64))]
-
-
-class CircuitDesc(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_uint32) for k in (
-        "degree_bits", "num_wires", "num_routed", "num_constants", "num_challenges", "quotient_degree_factor",
-        "num_partial_products", "num_public_inputs", "num_gate_constraints", "zero_knowledge", "fri_rate_bits",
-        "fri_cap_height", "fri_num_queries", "fri_pow_bits", "fri_num_layers")] + [
-        ("fri_arity_bits", ctypes.c_uint32 * 8), ("num_gates", ctypes.c_uint32), ("num_selector_groups", ctypes.c_uint32),
-        ("gates", ctypes.POINTER(Gate)), ("selector_indices", u32p), ("selector_group_ranges", u32p),
-        ("k_is", u64p), ("constants_sigmas", u64p), ("circuit_digest", ctypes.c_uint64 * 4)]
-
-
-class SynthParams(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_uint32) for k in ("degree_bits", "zero_knowledge", "n_poseidon", "n_basesum", "n_arith",
-                                               "n_constant", "n_copies", "fri_num_layers")] + [
-        ("fri_arity_bits", ctypes.c_uint32 * 8), ("circuit_seed", ctypes.c_uint64), ("fri_cap_height", ctypes.c_uint32),
-        ("fri_num_queries", ctypes.c_uint32), ("fri_pow_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
-        ("n_recursion", ctypes.c_uint32 * 8)]
-
-
-class ProveOpts(ctypes.Structure):
-    _fields_ = [("salts", u64p), ("salt_seed", ctypes.c_uint64), ("pow_witness", ctypes.c_uint64),
-                ("have_pow_witness", ctypes.c_uint32), ("wires_on_device", ctypes.c_uint32), ("stream", ctypes.c_void_p)]
-
-
-def ptr(a, t=u64p):
-    return a.ctypes.data_as(t)
-
-
-_oracle = None
-def oracle():
-    """liboracle.so — the CPU checker (builds it on first use with oracle/Makefile)."""
-    global _oracle
-    if _oracle is None:
-        so = os.path.join(ROOT, "oracle", "liboracle.so")
-        if not os.path.exists(so):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-j8"], stdout=subprocess.DEVNULL)
-        L = ctypes.CDLL(so)
-        L.orc_last_error.restype = ctypes.c_char_p
-        L.orc_mul.restype = L.orc_mul_slow.restype = L.orc_inv.restype = L.orc_root.restype = ctypes.c_uint64
-        L.orc_mul.argtypes = L.orc_mul_slow.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
-        L.orc_inv.argtypes = [ctypes.c_uint64]
-        L.orc_coset_lde.argtypes = [u64p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, u64p]
-        L.orc_ntt.argtypes = [u64p, ctypes.c_size_t, ctypes.c_int]
-        L.orc_merkle.restype = ctypes.c_size_t
-        L.orc_merkle.argtypes = [u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, u64p]
-        L.orc_hash_no_pad.argtypes = [u64p, ctypes.c_size_t, u64p]
-        L.orc_hash_or_noop.argtypes = [u64p, ctypes.c_size_t, u64p]
-        L.orc_proof_roundtrip.restype = ctypes.c_long
-        L.orc_circuit_create.restype = ctypes.c_void_p
-        L.orc_circuit_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p, ctypes.c_int]
-        L.orc_verifier_create.restype = ctypes.c_void_p
-        L.orc_verifier_create.argtypes = [ctypes.c_int] * 15 + [u32p, ctypes.c_int, u32p, u64p, u64p, u32p, ctypes.c_int, u32p, u64p, u64p, u64p]
-        L.orc_circuit_destroy.argtypes = [ctypes.c_void_p]
-        L.orc_circuit_cap.argtypes = [ctypes.c_void_p, u64p]
-        L.orc_prove.restype = ctypes.c_long
-        L.orc_prove.argtypes = [ctypes.c_void_p, u64p, u64p, u64p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
-        L.orc_verify.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
-        _oracle = L
-    return _oracle
-
-
-_synth = None
-def synth():
-    global _synth
-    if _synth is None:
-        L = ctypes.CDLL(os.path.join(PKG, "libqpsynth.so"))
-        L.qpsynth_last_error.restype = ctypes.c_char_p
-        L.qpsynth_preset.argtypes = [ctypes.c_char_p, ctypes.POINTER(SynthParams)]
-        L.qpsynth_circuit_create.argtypes = [ctypes.POINTER(SynthParams), ctypes.POINTER(ctypes.c_void_p)]
-        L.qpsynth_circuit_destroy.argtypes = [ctypes.c_void_p]
-        L.qpsynth_circuit_desc.restype = ctypes.POINTER(CircuitDesc)
-        L.qpsynth_circuit_desc.argtypes = [ctypes.c_void_p]
-        L.qpsynth_witness.argtypes = [ctypes.c_void_p, ctypes.c_uint64, u64p, u64p]
-        L.qpsynth_salts.argtypes = [ctypes.c_void_p, ctypes.c_uint64, u64p]
-        _synth = L
-    return _synth
-
-
-class SynthCircuit:
-    """A synthetic circuit package + witness source (include/qpsynth.h)."""
-
-    def __init__(self, preset=None, **overrides):
-        S = synth()
-        self.params = SynthParams()
-        if preset is not None and S.qpsynth_preset(preset.encode(), ctypes.byref(self.params)) != 0:
-            raise ValueError(S.qpsynth_last_error().decode())
-        for k, v in overrides.items():
-            if k == "fri_arity_bits":
-                for i in range(8):
-                    self.params.fri_arity_bits[i] = v[i] if i < len(v) else 0
-                self.params.fri_num_layers = len(v)
-            elif k == "n_recursion":
-                for i, a in enumerate(v):
-                    self.params.n_recursion[i] = a
-            else:
-                setattr(self.params, k, v)
-        h = ctypes.c_void_p()
-        if S.qpsynth_circuit_create(ctypes.byref(self.params), ctypes.byref(h)) != 0:
-            raise ValueError(S.qpsynth_last_error().decode())
-        self.handle = h
-        self.desc = S.qpsynth_circuit_desc(h).contents
-        d = self.desc
-        self.n = 1 << d.degree_bits
-        self.N = self.n << d.fri_rate_bits
-        self.W = d.num_wires
-
-    def witness(self, seed):
-        wires = np.zeros((self.W, self.n), dtype=np.uint64)
-        pis = np.zeros(self.desc.num_public_inputs, dtype=np.uint64)
-        synth().qpsynth_witness(self.handle, seed, ptr(wires), ptr(pis))
-        return wires, pis
-
-    def salts(self, salt_seed):
-        out = np.zeros((3, 4, self.N), dtype=np.uint64)
-        synth().qpsynth_salts(self.handle, salt_seed, ptr(out))
-        return out
-
-    def constants_sigmas(self):
-        d = self.desc
-        S = d.num_constants + d.num_routed
-        return np.ctypeslib.as_array(d.constants_sigmas, shape=(S, self.n))
-
-    def __del__(self):
-        try:
-            synth().qpsynth_circuit_destroy(self.handle)
-        except Exception:
-            pass
-
-
-class OracleCircuit:
-    """The CPU oracle's view of a circuit package: prove / verify with the restated qp-plonky2 algorithm."""
-
-    def __init__(self, desc, threads=0, verifier_only_cap=None):
-        L = oracle()
-        d = desc
-        ng = d.num_gates
-        tags = np.array([d.gates[i].tag for i in range(ng)], dtype=np.uint32)
-        params = np.array([d.gates[i].param for i in range(ng)], dtype=np.uint64)
-        extra = np.zeros((ng, 20), dtype=np.uint64)          # oracle/capi.cc ORC_GATE_EXTRA_STRIDE: {p2, p3, table_len, table...}
-        for i in range(ng):
-            g = d.gates[i]
-            extra[i, 0], extra[i, 1], extra[i, 2] = g.param2, g.param3, g.table_len
-            for k in range(g.table_len):
-                extra[i, 3 + k] = g.table[k]
-        arity = np.array(list(d.fri_arity_bits), dtype=np.uint32)
-        digest = np.array(list(d.circuit_digest), dtype=np.uint64)
-        self.desc = d
-        if verifier_only_cap is not None:
-            cap = np.ascontiguousarray(verifier_only_cap, dtype=np.uint64)
-            self.h = L.orc_verifier_create(d.degree_bits, d.num_wires, d.num_routed, d.num_constants, d.num_challenges,
-                                           d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
-                                           d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
-                                           d.fri_num_queries, d.fri_pow_bits, d.fri_num_layers, ptr(arity, u32p), ng,
-                                           ptr(tags, u32p), ptr(params), ptr(extra), d.selector_indices, d.num_selector_groups,
-                                           d.selector_group_ranges, d.k_is, ptr(cap), ptr(digest))
-            return
-        self.h = L.orc_circuit_create(d.degree_bits, d.num_wires, d.num_routed, d.num_constants, d.num_challenges,
-                                      d.quotient_degree_factor, d.num_partial_products, d.num_public_inputs,
-                                      d.num_gate_constraints, d.zero_knowledge, d.fri_rate_bits, d.fri_cap_height,
-                                      d.fri_num_queries, d.fri_pow_bits, d.fri_num_layers, ptr(arity, u32p), ng,
-                                      ptr(tags, u32p), ptr(params), ptr(extra), d.selector_indices, d.num_selector_groups,
-                                      d.selector_group_ranges, d.k_is, d.constants_sigmas, ptr(digest), threads)
-        if not self.h:
-            raise RuntimeError(L.orc_last_error().decode())
-
-    def prove(self, wires, pis, salts=None, pow_witness=None, threads=0):
-        L = oracle()
-        buf = ctypes.create_string_buffer(1 << 20)
-        wires = np.ascontiguousarray(wires, dtype=np.uint64)
-        n = L.orc_prove(self.h, ptr(wires), ptr(pis), ptr(salts) if salts is not None else None,
-                        0 if pow_witness is None else 1, 0 if pow_witness is None else pow_witness, threads, buf, len(buf))
-        if n < 0:
-            raise RuntimeError(L.orc_last_error().decode())
-        return buf.raw[:n]
-
-    def verify(self, proof):
-        L = oracle()
-        r = L.orc_verify(self.h, proof, len(proof))
-        return None if r == 0 else L.orc_last_error().decode()
-
-    def cap(self):
-        out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
-        oracle().orc_circuit_cap(self.h, ptr(out))
-        return out
-
-    def __del__(self):
-        try:
-            oracle().orc_circuit_destroy(self.h)
-        except Exception:
-            pass
-
-
-_qpgpu = None
-def qpgpu():
-    """libqpgpu.so — the product: HIP kernels + C-ABI (include/qpgpu.h). Fails loudly if it is not built."""
-    global _qpgpu
-    if _qpgpu is None:
-        so = os.path.join(PKG, "libqpgpu.so")
-        if not os.path.exists(so):
-            raise RuntimeError("libqpgpu.so missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        L = ctypes.CDLL(so)
-        L.qpgpu_last_error.restype = ctypes.c_char_p
-        L.qpgpu_test_permute.argtypes = [u64p, ctypes.c_size_t]
-        L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        L.qpgpu_test_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
-        L.qpgpu_test_merkle.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
-        L.qpgpu_test_intt_natural.argtypes = [u64p, ctypes.c_int, ctypes.c_int, u64p]
-        L.qpgpu_test_bitrev.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
-        L.qpgpu_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
-        L.qpgpu_ctx_destroy.argtypes = [ctypes.c_void_p]
-        L.qpgpu_circuit_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(CircuitDesc), ctypes.POINTER(ctypes.c_void_p)]
-        L.qpgpu_circuit_destroy.argtypes = [ctypes.c_void_p]
-        L.qpgpu_circuit_constants_sigmas_cap.argtypes = [ctypes.c_void_p, u64p]
-        L.qpgpu_proof_size.restype = ctypes.c_size_t
-        L.qpgpu_proof_size.argtypes = [ctypes.c_void_p]
-        L.qpgpu_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.POINTER(ProveOpts),
-                                  ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
-        L.qpgpu_prove_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64p),
-                                        ctypes.c_size_t, ctypes.POINTER(ProveOpts), ctypes.c_char_p, ctypes.c_size_t,
-                                        ctypes.POINTER(ctypes.c_size_t)]
-        L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
-        _qpgpu = L
-    return _qpgpu
-
-
-class GpuCircuit:
-    """qpgpu_ctx + qpgpu_circuit: the product's resident circuit handle (include/qpgpu.h)."""
-
-    def __init__(self, desc, device=0):
-        L = qpgpu()
-        self.desc = desc
-        self.ctx = ctypes.c_void_p()
-        gpu_check(L.qpgpu_ctx_create(device, ctypes.byref(self.ctx)))
-        self.h = ctypes.c_void_p()
-        gpu_check(L.qpgpu_circuit_create(self.ctx, ctypes.byref(desc), ctypes.byref(self.h)))
-        self.proof_size = L.qpgpu_proof_size(self.h)
-
-    def cap(self):
-        out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
-        gpu_check(qpgpu().qpgpu_circuit_constants_sigmas_cap(self.h, ptr(out)))
-        return out
-
-    def prove(self, wires, pis, salts=None, salt_seed=0, pow_witness=None, wires_dev_ptr=None, stream=None):
-        L = qpgpu()
-        o = ProveOpts()
-        o.salts = ptr(salts) if salts is not None else None
-        o.salt_seed = salt_seed
-        o.have_pow_witness = 0 if pow_witness is None else 1
-        o.pow_witness = 0 if pow_witness is None else pow_witness
-        o.wires_on_device = 0 if wires_dev_ptr is None else 1
-        o.stream = stream
-        if wires_dev_ptr is None:
-            wires = np.ascontiguousarray(wires, dtype=np.uint64)
-            wp = wires.ctypes.data
-        else:
-            wp = wires_dev_ptr
-        buf = ctypes.create_string_buffer(self.proof_size)
-        n = ctypes.c_size_t()
-        gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
-        return ctypes.string_at(buf, n.value)          # one copy (buf.raw[:n] makes two)
-
-    def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False):
-        L = qpgpu()
-        b = len(pis_list)
-        o = ProveOpts()
-        o.salt_seed = salt_seed
-        o.wires_on_device = 1 if wires_on_device else 0
-        if wires_on_device:
-            wp = (ctypes.c_void_p * b)(*wires_list)
-        else:
-            wires_list = [np.ascontiguousarray(w, dtype=np.uint64) for w in wires_list]
-            wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in wires_list])
-        pp = (u64p * b)(*[ptr(p) for p in pis_list])
-        buf = ctypes.create_string_buffer(self.proof_size * b)
-        lens = (ctypes.c_size_t * b)()
-        gpu_check(L.qpgpu_prove_batch(self.h, b, wp, pp, len(pis_list[0]), ctypes.byref(o), buf, self.proof_size, lens))
-        return [ctypes.string_at(ctypes.addressof(buf) + i * self.proof_size, self.proof_size) for i in range(b)]
-
-    def stage_ms(self):
-        out = (ctypes.c_double * 16)()
-        k = qpgpu().qpgpu_last_stage_ms(out, 16)
-        return list(out[:k])
-
-    def close(self):
-        L = qpgpu()
-        if self.h:
-            L.qpgpu_circuit_destroy(self.h); self.h = None
-        if self.ctx:
-            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
-def gpu_check(rc):
-    if rc != 0:
-        raise RuntimeError("qpgpu error %d: %s" % (rc, qpgpu().qpgpu_last_error().decode()))
+P = _ffi.P
+u64p, u32p, u8p, ptr = _ffi.u64p, _ffi.u32p, _ffi.u8p, _ffi.ptr
+Gate, CircuitDesc, SynthParams, ProveOpts = _ffi.Gate, _ffi.CircuitDesc, _ffi.SynthParams, _ffi.ProveOpts
+qpgpu, synth, gpu_check = _ffi.qpgpu, _ffi.synth, _ffi.gpu_check
+SynthCircuit, GpuCircuit, ReferenceCircuitShape, replay_transcript = _ffi.SynthCircuit, _ffi.GpuCircuit, _ffi.ReferenceCircuitShape, _ffi.replay_transcript
 
 
 def rand_felts(rng, shape):

@@ -22,6 +22,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(S, s), s
 
 
+def test_library_exports_nothing_undeclared():
+    """The C symbols of libqpgpu.so are exactly include/qpgpu.h (the drop-in ABI) + include/qpgpu_internal.h (transcript replay,
+    profiling counters, kernel test hooks) — no stray test or helper symbol rides along."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(PKG, "libqpgpu.so")], capture_output=True, text=True).stdout
+    exported = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and not l.split()[2].startswith("_Z")}
+    declared = set(declared_symbols("qpgpu.h")) | set(declared_symbols("qpgpu_internal.h"))
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    internal = set(declared_symbols("qpgpu_internal.h")) - set(declared_symbols("qpgpu.h"))
+    assert all(s.startswith(("qpgpu_test_", "qpgpu_bench_", "qpgpu_profile_", "qpgpu_replay_", "qpgpu_last_stage")) for s in internal), sorted(internal)
+
+
 def test_product_library_does_not_link_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(PKG, "libqpgpu.so")], capture_output=True, text=True).stdout
@@ -29,6 +41,11 @@ def test_product_library_does_not_link_the_oracle():
     for f in os.listdir(os.path.join(PKG, "csrc")):
         if f.endswith((".hip", ".h", ".cc")):
             assert "oracle/" not in open(os.path.join(PKG, "csrc", f)).read()
+    for dirpath, _, files in os.walk(PKG):                      # the Python side of the product never imports the checker either
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) and "liboracle" not in src, f
 
 
 def test_null_arguments_do_not_crash():

@@ -1,5 +1,19 @@
-import sys; sys.path.insert(0,"tests")
+#!/usr/bin/env python3
+"""Saturated throughput of the one-permutation-per-lane Poseidon kernel on this GPU (qpgpu_bench_permute, grid sweep), written next to the
+first-principles issue bound of tools/poseidon_issue_bound.py: profiles/r02_poseidon_issue_bound.json gains
+measured_saturated_G_perm_per_s (bench.py reads both for its valu_roofline object). Run on the GPU box; copy the JSON back."""
+import importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch; torch.cuda.init()
-import harness as H, ctypes
-L=H.qpgpu(); L.qpgpu_bench_permute.restype=ctypes.c_double; L.qpgpu_bench_permute.argtypes=[ctypes.c_size_t, ctypes.c_int]
-print("G perm/s:", [(cnt, round(L.qpgpu_bench_permute(cnt, 10),3)) for cnt in (1<<16, 1<<17, 1<<18, 1<<20, 1<<22)])
+H = importlib.import_module("zk-circuits_amd.ffi")
+L = H.qpgpu()
+sweep = [(cnt, round(L.qpgpu_bench_permute(cnt, 10), 3)) for cnt in (1 << 16, 1 << 17, 1 << 18, 1 << 20, 1 << 22, 1 << 23)]
+print("G perm/s:", sweep)
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_poseidon_issue_bound.json")
+src = os.path.join(ROOT, "profiles", "r02_poseidon_issue_bound.json")
+d = json.load(open(src)) if os.path.exists(src) else {}
+d["measured_sweep_G_perm_per_s"] = sweep
+d["measured_saturated_G_perm_per_s"] = max(v for _, v in sweep)
+d["measured_source"] = "tools/permute_rate.py (qpgpu_bench_permute: k_permute_batch, 10 launches per grid size) on MI355X"
+json.dump(d, open(out, "w"), indent=1)

@@ -1,5 +1,6 @@
 // Per-kernel test hooks (host buffers in, host buffers out). Not part of the drop-in ABI: they exist so tests/ can
 // compare each HIP kernel with its oracle twin bit for bit (SURVEY.md §4 implication (4)).
+#include "../../include/qpgpu_internal.h"
 #include "kernels.h"
 #include <vector>
 #include <string>
@@ -69,6 +70,42 @@ int qpgpu_test_merkle(const uint64_t* cols, int width, size_t num_leaves, int ca
   return 0;
 }
 
+// ---- golden-vector replay hooks: the device sponge / 2-to-1 / FRI-leaf kernels on caller-supplied rows, one kernel form at a
+// time, so tests can pin each form directly to vectors the reference holds (KATs, the Merkle paths of bench-data/proof.bin).
+// Leaf digests only (hash_or_noop per row). cols: [width][num_leaves] column-major. mode 0: per-lane kernel (plain), 1: 2-lane pair
+// kernel, 2: per-lane kernel with fused levels 1-2 (needs num_leaves % 256 == 0; only the leaf digests are returned).
+int qpgpu_test_leaf_hash(const uint64_t* cols, int width, size_t num_leaves, int mode, uint64_t* digests) {
+  if (!cols || !digests || width < 1 || num_leaves < 1 || mode < 0 || mode > 2 || (mode == 2 && num_leaves % 256)) return set_err(-1, "bad argument");
+  DevBuf c, d; HOOK_CHECK(c.alloc((size_t)width * num_leaves * 8)); HOOK_CHECK(d.alloc(num_leaves * 32 * 2));
+  HOOK_CHECK(hipMemcpy(c.p, cols, (size_t)width * num_leaves * 8, hipMemcpyHostToDevice));
+  merkle_leaves_colmajor_mode(c.u(), num_leaves, width, num_leaves, d.u(), mode, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(digests, d.p, num_leaves * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+// out[i] = two_to_one(pairs[i][0..4], pairs[i][4..8]). mode 0: per-lane, 1: 2-lane pair, 2: 16-lane cooperative, 3: fused multi-level
+// kernel (one level).
+int qpgpu_test_two_to_one(const uint64_t* pairs, size_t count, int mode, uint64_t* out) {
+  if (!pairs || !out || count < 1 || mode < 0 || mode > 3) return set_err(-1, "bad argument");
+  DevBuf a, b; HOOK_CHECK(a.alloc(count * 64)); HOOK_CHECK(b.alloc(count * 32));
+  HOOK_CHECK(hipMemcpy(a.p, pairs, count * 64, hipMemcpyHostToDevice));
+  merkle_level_mode(a.u(), b.u(), count, mode, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(out, b.p, count * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+// FRI layer leaves: leaf L = 2^arity_bits extension values (a[k], b[k]). mode 0: per-lane kernel, 1: 16-lane cooperative kernel.
+int qpgpu_test_fri_leaf_hash(const uint64_t* a, const uint64_t* b, int arity_bits, size_t num_leaves, int mode, uint64_t* digests) {
+  if (!a || !b || !digests || arity_bits < 1 || arity_bits > 4 || num_leaves < 1 || mode < 0 || mode > 1) return set_err(-1, "bad argument");
+  const size_t n = num_leaves << arity_bits;
+  DevBuf da, db, d; HOOK_CHECK(da.alloc(n * 8)); HOOK_CHECK(db.alloc(n * 8)); HOOK_CHECK(d.alloc(num_leaves * 32));
+  HOOK_CHECK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice)); HOOK_CHECK(hipMemcpy(db.p, b, n * 8, hipMemcpyHostToDevice));
+  merkle_leaves_fri_mode(da.u(), db.u(), arity_bits, num_leaves, d.u(), mode, 0);
+  HOOK_CHECK(hipGetLastError());
+  HOOK_CHECK(hipMemcpy(digests, d.p, num_leaves * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // host-side costs that sit on the proof's critical path: ns per host permutation, and us per (tiny kernel + 512 B D2H + sync)
 double qpgpu_test_host_permute_ns(int iters) {
   u64 st[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
@@ -134,7 +171,7 @@ int qpgpu_test_intt_natural(const uint64_t* vals, int count, int log_n, uint64_t
 // PMC calibration kernel: streams a [width][n] column-major matrix with the leaf kernel's access pattern (8 B per lane per
 // column) and writes one u64 per row, so FETCH_SIZE / WRITE_SIZE can be scaled against a known byte count
 // (MI355X_MICROARCH.md: FETCH_SIZE is only calibrated for 16 B/lane streams).
-__global__ void __launch_bounds__(256) k_calib_colsum(const u64* cols, size_t stride, int width, size_t n, u64* out) {
+static __global__ void __launch_bounds__(256) k_calib_colsum(const u64* cols, size_t stride, int width, size_t n, u64* out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 acc = 0;

@@ -61,6 +61,10 @@ void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_le
 // Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to
 // 2^cap_height digests. Returns (host-side) nothing; layout helper below.
 void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done = 0, bool batch = false);
+// Explicit kernel-form selection (tests/golden replay; production picks the form by size inside the functions above).
+void merkle_leaves_colmajor_mode(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, int mode, hipStream_t s);
+void merkle_level_mode(const u64* in, u64* out, size_t parents, int mode, hipStream_t s);
+void merkle_leaves_fri_mode(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, int mode, hipStream_t s);
 static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
   size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
 }

@@ -327,4 +327,22 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
   }
 }
 
+// ---- explicit kernel-form selection (kernels.h): one launch of the named form, whatever the size
+void merkle_leaves_colmajor_mode(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, int mode, hipStream_t s) {
+  dim3 grid((unsigned)((num_leaves + 255) / 256));
+  if (mode == 1) hipLaunchKernelGGL(k_leaves_colmajor_pair, dim3((unsigned)((2 * num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
+  else if (mode == 2) hipLaunchKernelGGL(k_leaves_colmajor<true>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4, digests + (num_leaves + num_leaves / 2) * 4);
+  else hipLaunchKernelGGL(k_leaves_colmajor<false>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+}
+void merkle_level_mode(const u64* in, u64* out, size_t parents, int mode, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, in, out, parents);
+  else if (mode == 1) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, in, out, parents);
+  else if (mode == 2) hipLaunchKernelGGL(k_level_coop, dim3((unsigned)((parents + 3) / 4)), dim3(64), 0, s, in, out, parents);
+  else hipLaunchKernelGGL(k_levels_coop_fused<32>, dim3((unsigned)((parents + 31) / 32)), dim3(512), 0, s, in, out, parents, 1);
+}
+void merkle_leaves_fri_mode(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, int mode, hipStream_t s) {
+  if (mode == 1) hipLaunchKernelGGL(k_leaves_fri_coop, dim3((unsigned)((num_leaves + 3) / 4)), dim3(64), 0, s, a, b, arity_bits, num_leaves, digests);
+  else hipLaunchKernelGGL(k_leaves_fri, dim3((unsigned)((num_leaves + 255) / 256)), dim3(256), 0, s, a, b, arity_bits, num_leaves, digests);
+}
+
 } // namespace qp

@@ -6,7 +6,7 @@
 // query gather) runs as HIP kernels on a per-call stream with a per-call workspace. The Fiat-Shamir transcript
 // (row a6, ~120 sequential Poseidon permutations per proof) is inherently serial, so it runs on the host between
 // stages, exactly where upstream's Challenger runs; each challenge costs one small D2H copy of a cap / opening set.
-#include "../../include/qpgpu.h"
+#include "../../include/qpgpu_internal.h"
 #include "kernels.h"
 #include "poseidon.h"
 #include <string>
@@ -36,6 +36,30 @@ struct Challenger {
   void observe_n(const u64* p, size_t k) { for (size_t i = 0; i < k; i++) observe(p[i]); }
   u64 challenge() { if (n_in > 0 || n_out == 0) duplex(); return out[--n_out]; }
   Ext challenge_ext() { u64 a = challenge(); u64 b = challenge(); return ex(a, b); }
+};
+
+// The proof's Fiat-Shamir schedule, shared by the prover below and by qpgpu_replay_transcript (which
+// re-derives every challenge from finished proof bytes, e.g. the reference's golden bench-data/proof.bin).
+struct Transcript {
+  Challenger ch; int nch;
+  explicit Transcript(int nch_) : nch(nch_) {}
+  void start(const u64 digest[4], const u64 pi_hash[4], const u64* wires_cap, size_t cap_words, u64* betas, u64* gammas) {
+    ch.observe_n(digest, 4); ch.observe_n(pi_hash, 4); ch.observe_n(wires_cap, cap_words);
+    for (int i = 0; i < nch; i++) betas[i] = ch.challenge();
+    for (int i = 0; i < nch; i++) gammas[i] = ch.challenge();
+  }
+  void after_zs_cap(const u64* cap, size_t cap_words, u64* alphas) { ch.observe_n(cap, cap_words); for (int i = 0; i < nch; i++) alphas[i] = ch.challenge(); }
+  Ext after_quotient_cap(const u64* cap, size_t cap_words) { ch.observe_n(cap, cap_words); return ch.challenge_ext(); }
+  // openings in proof order: constants|sigmas|wires|zs (a ext values), zs_next (nch), partial products|quotient (b ext values);
+  // observed as constants..zs, partial products, quotient, then zs_next
+  Ext after_openings(const u64* op, size_t a_ext, size_t b_ext) {
+    ch.observe_n(op, 2 * a_ext); ch.observe_n(op + 2 * a_ext + 2 * (size_t)nch, 2 * b_ext); ch.observe_n(op + 2 * a_ext, 2 * (size_t)nch);
+    return ch.challenge_ext();
+  }
+  Ext fri_layer_cap(const u64* cap, size_t cap_words) { ch.observe_n(cap, cap_words); return ch.challenge_ext(); }
+  void final_poly_coeff(u64 a, u64 b) { ch.observe(a); ch.observe(b); }
+  u64 pow_response(u64 pow_witness) { ch.observe(pow_witness); return ch.challenge(); }
+  u32 query_index(size_t N) { return (u32)(ch.challenge() % N); }
 };
 
 struct Layout {   // ProofWithPublicInputs::to_bytes() layout
@@ -256,6 +280,23 @@ static void values_to_coeffs(qpgpu_circuit* c, Workspace* w, const u64* vals, in
   bitrev_permute(tmp, c->n, coeffs, c->n, cols, c->log_n, gl_inv((u64)c->n), s);
 }
 
+// ProofWithPublicInputs::to_bytes() offsets from the CommonCircuitData shape alone.
+static void compute_layout(const qpgpu_circuit_desc& d, Layout& L) {
+  const int log_n = d.degree_bits, rate = d.fri_rate_bits, cap_h = d.fri_cap_height, nch = d.num_challenges, salt = d.zero_knowledge ? 4 : 0;
+  const size_t S = (size_t)d.num_constants + d.num_routed, W = d.num_wires, Zp = (size_t)nch * (1 + d.num_partial_products), Q = (size_t)nch * d.quotient_degree_factor;
+  const size_t capn = size_t(1) << cap_h;
+  L.cap_bytes = capn * 32; L.openings_off = 3 * L.cap_bytes;
+  L.n_openings = S + W + 2 * nch + (size_t)nch * d.num_partial_products + Q;
+  L.fri_caps_off = L.openings_off + 16 * L.n_openings; L.queries_off = L.fri_caps_off + (size_t)d.fri_num_layers * L.cap_bytes;
+  size_t path = log_n + rate - cap_h; const size_t widths[4] = {S, W + salt, Zp + salt, Q + salt};
+  size_t b = 0; for (int t = 0; t < 4; t++) b += 8 * widths[t] + 1 + 32 * path;
+  int lg = log_n;
+  for (uint32_t l = 0; l < d.fri_num_layers; l++) { const int a = d.fri_arity_bits[l]; size_t fp = lg + rate - a - cap_h; b += (size_t(16) << a) + 1 + 32 * fp; lg -= a; }
+  L.bytes_per_query = b;
+  L.final_poly_off = L.queries_off + L.bytes_per_query * d.fri_num_queries; L.final_poly_len = size_t(1) << lg;
+  L.pow_off = L.final_poly_off + 16 * L.final_poly_len; L.pis_off = L.pow_off + 8; L.total = L.pis_off + 8 + 8 * (size_t)d.num_public_inputs;
+}
+
 // No C++ exception may cross the C ABI (include/qpgpu.h): host allocation failures and the like become status codes.
 template <class F> static int abi_guard(F&& f) {
   try { return f(); }
@@ -361,16 +402,8 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
     if (c->fri_log_n[l] + c->rate - c->arity[l] < c->cap_h) { delete c; return set_err(QPGPU_ERR_ARG, "FRI layer tree smaller than its cap"); }
   }
   // ---- layout
-  Layout& L = c->lay; const size_t capn = size_t(1) << c->cap_h;
-  L.cap_bytes = capn * 32; L.openings_off = 3 * L.cap_bytes;
-  L.n_openings = (size_t)c->S + c->W + 2 * c->nch + (size_t)c->nch * d.num_partial_products + c->Q;
-  L.fri_caps_off = L.openings_off + 16 * L.n_openings; L.queries_off = L.fri_caps_off + (size_t)c->nlayers * L.cap_bytes;
-  { size_t path = c->log_N - c->cap_h; size_t widths[4] = {(size_t)c->S, (size_t)c->W + c->salt, (size_t)c->Zp + c->salt, (size_t)c->Q + c->salt};
-    size_t b = 0; for (int t = 0; t < 4; t++) b += 8 * widths[t] + 1 + 32 * path;
-    for (int l = 0; l < c->nlayers; l++) { size_t fp = c->fri_log_n[l] + c->rate - c->arity[l] - c->cap_h; b += (size_t(16) << c->arity[l]) + 1 + 32 * fp; }
-    L.bytes_per_query = b; }
-  L.final_poly_off = L.queries_off + L.bytes_per_query * d.fri_num_queries; L.final_poly_len = size_t(1) << c->fri_log_n[c->nlayers];
-  L.pow_off = L.final_poly_off + 16 * L.final_poly_len; L.pis_off = L.pow_off + 8; L.total = L.pis_off + 8 + 8 * (size_t)d.num_public_inputs;
+  compute_layout(d, c->lay);
+  const size_t capn = size_t(1) << c->cap_h;
   // ---- device constants
   hipStream_t s = 0;
 #define CC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(e_); qpgpu_circuit_destroy(c); return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, m); } } while (0)
@@ -439,7 +472,7 @@ struct ByteReader {
   uint32_t u32_() { if (pos + 4 > len) { ok = false; return 0; } uint32_t v; memcpy(&v, b + pos, 4); pos += 4; return v; }
   uint8_t u8_() { if (pos + 1 > len) { ok = false; return 0; } return b[pos++]; }
 };
-bool read_fri_config(ByteReader& r, uint32_t out[4]) {
+static bool read_fri_config(ByteReader& r, uint32_t out[4]) {
   out[0] = (uint32_t)r.u64_(); out[1] = (uint32_t)r.u64_(); out[2] = (uint32_t)r.u64_(); out[3] = r.u32_();
   uint8_t tag = r.u8_();
   if (tag == 0) { uint64_t k = r.u64_(); for (uint64_t i = 0; i < k && r.ok; i++) r.u64_(); }
@@ -523,7 +556,7 @@ size_t qpgpu_proof_size(const qpgpu_circuit* c) { return c ? c->lay.total : 0; }
 
 // ------------------------------------------------------------------------------------------------ prove
 static thread_local double g_stage_ms[16]; static thread_local int g_stage_n = 0;
-extern "C" int qpgpu_last_stage_ms(double* out, int cap) { int k = g_stage_n < cap ? g_stage_n : cap; for (int i = 0; i < k; i++) out[i] = g_stage_ms[i]; return g_stage_n; }
+int qpgpu_last_stage_ms(double* out, int cap) { int k = g_stage_n < cap ? g_stage_n : cap; for (int i = 0; i < k; i++) out[i] = g_stage_ms[i]; return g_stage_n; }
 
 static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64_t* wires, const uint64_t* pis, const qpgpu_prove_opts* opts,
                      u64 salt_seed, const u64* salts_host, uint8_t* out) {
@@ -551,11 +584,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out, pin, L.cap_bytes);
-  Challenger ch;
-  ch.observe_n((const u64*)d.circuit_digest, 4); ch.observe_n(pi_hash, 4); ch.observe_n(pin, capn * 4);
+  Transcript tr(nch); Challenger& ch = tr.ch;
   Chal2 betas{{0, 0}}, gammas{{0, 0}}, alphas{{0, 0}};
-  for (int i = 0; i < nch; i++) betas.v[i] = ch.challenge();
-  for (int i = 0; i < nch; i++) gammas.v[i] = ch.challenge();
+  tr.start((const u64*)d.circuit_digest, pi_hash, pin, capn * 4, betas.v, gammas.v);
   // ---- 4: Z / partial products
   { ProfScope ps(w, s, PF_ZPP, 8.0 * n * (2.0 * d.num_routed + c->Zp));
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
@@ -569,8 +600,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->zs_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + L.cap_bytes, pin, L.cap_bytes);
-  ch.observe_n(pin, capn * 4);
-  for (int i = 0; i < nch; i++) alphas.v[i] = ch.challenge();
+  tr.after_zs_cap(pin, capn * 4, alphas.v);
   // ---- 6: quotient
   const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
   alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
@@ -599,8 +629,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
-  ch.observe_n(pin, capn * 4);
-  Ext zeta = ch.challenge_ext();
+  Ext zeta = tr.after_quotient_cap(pin, capn * 4);
   if (ex_eq(ex_pow(zeta, n), ex(1, 0))) return set_err(QPGPU_ERR_ZETA, "zeta lies in the trace subgroup");
   // ---- 8: openings
   const Ext gzeta = ex_scale(zeta, gl_root(c->log_n));
@@ -627,14 +656,8 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { int rc_ = fetch_to_host(w, s, w->openings, 2 * L.n_openings); if (rc_) return rc_; }
   mark();
   memcpy(out + L.openings_off, pin, 16 * L.n_openings);
-  {
-    const size_t a = 2 * ((size_t)c->S + c->W + nch);          // constants..zs
-    ch.observe_n(pin, a);
-    ch.observe_n(pin + a + 2 * nch, 2 * ((size_t)nch * npp + c->Q));   // partial products, quotient
-    ch.observe_n(pin + a, 2 * (size_t)nch);                    // zs_next
-  }
   // ---- 9: FRI
-  const Ext fa = ch.challenge_ext();
+  const Ext fa = tr.after_openings(pin, (size_t)c->S + c->W + nch, (size_t)nch * npp + c->Q);
   {
     ProfScope ps(w, s, PF_FRI_COMBINE, 8.0 * n * (c->S + c->W + c->Zp + c->Q + nch + 24));
     fri_compose(PolyGroup{c->d_cs_coeffs, n, c->S}, PolyGroup{w->wires_coeffs, n, c->W}, PolyGroup{w->zs_coeffs, n, c->Zp},
@@ -653,8 +676,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     }
     { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->fri_dig[l], leaves), capn * 4); if (rc_) return rc_; }
     memcpy(out + L.fri_caps_off + (size_t)l * L.cap_bytes, pin, L.cap_bytes);
-    ch.observe_n(pin, capn * 4);
-    fri_betas[l] = ch.challenge_ext();
+    fri_betas[l] = tr.fri_layer_cap(pin, capn * 4);
     const size_t nn = nl >> c->arity[l];
     fri_fold(w->fri_coeffs[l], w->fri_coeffs[l] + nl, nn, c->arity[l], fri_betas[l], w->fri_coeffs[l + 1], w->fri_coeffs[l + 1] + nn, s);
   }
@@ -662,7 +684,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     const size_t fl = L.final_poly_len;
     { int rc_ = fetch_to_host(w, s, w->fri_coeffs[c->nlayers], 2 * fl); if (rc_) return rc_; }
     u64* fp = (u64*)(out + L.final_poly_off);
-    for (size_t i = 0; i < fl; i++) { u64 a = pin[i], b = pin[fl + i]; memcpy(&fp[2 * i], &a, 8); memcpy(&fp[2 * i + 1], &b, 8); ch.observe(a); ch.observe(b); }
+    for (size_t i = 0; i < fl; i++) { u64 a = pin[i], b = pin[fl + i]; memcpy(&fp[2 * i], &a, 8); memcpy(&fp[2 * i + 1], &b, 8); tr.final_poly_coeff(a, b); }
   }
   mark();
   // ---- PoW
@@ -684,9 +706,8 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     }
     if (pow_witness == none) return set_err(QPGPU_ERR_POW, "proof-of-work grind found no witness");
   }
-  ch.observe(pow_witness);
   {
-    u64 resp = ch.challenge();
+    u64 resp = tr.pow_response(pow_witness);
     int lz = resp == 0 ? 64 : __builtin_clzll(resp);
     if (lz < (int)d.fri_pow_bits) return set_err(QPGPU_ERR_POW, "supplied pow_witness does not meet proof_of_work_bits");
   }
@@ -704,7 +725,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     ga.layers[l] = GatherFri{w->fri_vals[l], w->fri_vals[l] + Nl, w->fri_dig[l], c->arity[l], c->fri_log_n[l] + c->rate - c->arity[l]};
   }
   ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query; ga.pow_reset = w->pow_result;
-  for (int q = 0; q < ga.nq; q++) ga.idx[q] = (u32)(ch.challenge() % N);
+  for (int q = 0; q < ga.nq; q++) ga.idx[q] = tr.query_index(N);
   { ProfScope ps(w, s, PF_GATHER, 2.0 * L.bytes_per_query * ga.nq); query_gather(ga, w->query_bytes, s); }
   { int rc_ = fetch_to_host(w, s, (const u64*)w->query_bytes, (L.bytes_per_query * ga.nq + 7) / 8); if (rc_) return rc_; }
   HIP_TRY(hipGetLastError());
@@ -722,6 +743,47 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
 }
 
 extern "C" {
+
+// Re-derives the Fiat-Shamir challenges of a finished proof with the prover's own Transcript (host only, no device work).
+// out: pi_hash[4] | betas[nch] | gammas[nch] | alphas[nch] | zeta[2] | fri_alpha[2] | fri_betas[2*layers] | pow_response | indices[queries].
+// Returns the number of words written, or a negative status. Declared in include/qpgpu_internal.h.
+int qpgpu_replay_transcript(const qpgpu_circuit_desc* dp, const uint8_t* proof, size_t len, uint64_t* out, size_t out_cap) { return abi_guard([&]() -> int {
+  if (!dp || !proof || !out) return set_err(QPGPU_ERR_ARG, "null argument");
+  const qpgpu_circuit_desc& d = *dp;
+  if (d.num_challenges < 1 || d.num_challenges > 2 || d.fri_num_layers > MAX_FRI_LAYERS || d.fri_cap_height > 20 || d.degree_bits + d.fri_rate_bits > 28)
+    return set_err(QPGPU_ERR_ARG, "unsupported shape");
+  { uint32_t sum = 0; for (uint32_t i = 0; i < d.fri_num_layers; i++) sum += d.fri_arity_bits[i]; if (sum > d.degree_bits) return set_err(QPGPU_ERR_ARG, "FRI reductions exceed degree"); }
+  Layout L; compute_layout(d, L);
+  if (len != L.total) return set_err(QPGPU_ERR_ARG, "proof length " + std::to_string(len) + " != " + std::to_string(L.total) + " for this circuit shape");
+  const int nch = d.num_challenges; const size_t capw = size_t(4) << d.fri_cap_height, N = size_t(1) << (d.degree_bits + d.fri_rate_bits);
+  const size_t need = 4 + 3 * (size_t)nch + 4 + 2 * (size_t)d.fri_num_layers + 1 + d.fri_num_queries;
+  if (out_cap < need) return set_err(QPGPU_ERR_BUFFER, "output too small");
+  std::vector<u64> words((len + 7) / 8 + 1); memcpy(words.data(), proof, len);       // caps and openings (everything before the query rounds) are 8-byte aligned
+  auto at = [&](size_t off) { return words.data() + off / 8; };
+  u64 npi; memcpy(&npi, proof + L.pis_off, 8);
+  if (npi != d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
+  size_t o = 0;
+  std::vector<u64> pis(d.num_public_inputs ? d.num_public_inputs : 1); memcpy(pis.data(), proof + L.pis_off + 8, 8 * (size_t)d.num_public_inputs);   // unaligned: follows the query rounds
+  u64 pi_hash[4]; hash_no_pad(pis.data(), d.num_public_inputs, pi_hash);
+  for (int i = 0; i < 4; i++) out[o++] = pi_hash[i];
+  Transcript tr(nch);
+  u64 betas[2], gammas[2], alphas[2];
+  tr.start((const u64*)d.circuit_digest, pi_hash, at(0), capw, betas, gammas);
+  for (int i = 0; i < nch; i++) out[o++] = betas[i];
+  for (int i = 0; i < nch; i++) out[o++] = gammas[i];
+  tr.after_zs_cap(at(L.cap_bytes), capw, alphas);
+  for (int i = 0; i < nch; i++) out[o++] = alphas[i];
+  Ext zeta = tr.after_quotient_cap(at(2 * L.cap_bytes), capw); out[o++] = zeta.a; out[o++] = zeta.b;
+  const size_t S = (size_t)d.num_constants + d.num_routed;
+  Ext fa = tr.after_openings(at(L.openings_off), S + d.num_wires + nch, (size_t)nch * d.num_partial_products + (size_t)nch * d.quotient_degree_factor);
+  out[o++] = fa.a; out[o++] = fa.b;
+  for (uint32_t l = 0; l < d.fri_num_layers; l++) { Ext b = tr.fri_layer_cap(at(L.fri_caps_off + l * L.cap_bytes), capw); out[o++] = b.a; out[o++] = b.b; }
+  for (size_t i = 0; i < L.final_poly_len; i++) { u64 a, b; memcpy(&a, proof + L.final_poly_off + 16 * i, 8); memcpy(&b, proof + L.final_poly_off + 16 * i + 8, 8); tr.final_poly_coeff(a, b); }
+  u64 pw; memcpy(&pw, proof + L.pow_off, 8);
+  out[o++] = tr.pow_response(pw);
+  for (uint32_t q = 0; q < d.fri_num_queries; q++) out[o++] = tr.query_index(N);
+  return (int)o;
+}); }
 
 // Per-kernel-group timing for bench.py's roofline object (HIP events on the proving stream; off by default).
 void qpgpu_profile_enable(int on) { g_prof_on.store(on); }

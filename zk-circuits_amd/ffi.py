@@ -1,11 +1,19 @@
-"""ctypes binding of include/qpgpu.h and include/qpsynth.h (the stub a reference maintainer would write in Rust with
-bindgen is shown in INTEGRATION.md)."""
+"""ctypes binding of include/qpgpu.h, include/qpgpu_internal.h and include/qpsynth.h — the one Python binding of the product
+(tests/harness.py and bench.py import it; the stub a reference maintainer would write in Rust with bindgen is in INTEGRATION.md).
+Nothing here touches oracle/ (that binding lives in oracle/binding.py, test infrastructure)."""
 import ctypes
 import os
+import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 u64p = ctypes.POINTER(ctypes.c_uint64)
 u32p = ctypes.POINTER(ctypes.c_uint32)
+u8p = ctypes.POINTER(ctypes.c_uint8)
+P = 0xFFFFFFFF00000001
+
+
+def ptr(a, t=u64p):
+    return a.ctypes.data_as(t)
 
 
 class QpgpuError(RuntimeError):
@@ -55,6 +63,7 @@ def lib():
             raise ImportError("zk-circuits_amd: %s not built — run `python -c \"import __graft_entry__ as g; g.build()\"` "
                               "(hipcc --offload-arch=gfx950)" % so)
         L = ctypes.CDLL(so)
+        # ---- include/qpgpu.h
         L.qpgpu_last_error.restype = ctypes.c_char_p
         L.qpgpu_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.qpgpu_ctx_destroy.argtypes = [ctypes.c_void_p]
@@ -68,6 +77,32 @@ def lib():
         L.qpgpu_prove_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(u64p), ctypes.c_size_t, ctypes.POINTER(ProveOpts), ctypes.c_char_p,
                                         ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_parse_common.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(CircuitDesc), ctypes.POINTER(Gate), ctypes.c_size_t,
+                                         u32p, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t]
+        L.qpgpu_parse_verifier_only.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        # ---- include/qpgpu_internal.h
+        L.qpgpu_replay_transcript.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t]
+        L.qpgpu_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.qpgpu_profile_name.restype = ctypes.c_char_p
+        L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        L.qpgpu_test_permute.argtypes = [u64p, ctypes.c_size_t]
+        L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.qpgpu_test_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
+        L.qpgpu_test_merkle.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_intt_natural.argtypes = [u64p, ctypes.c_int, ctypes.c_int, u64p]
+        L.qpgpu_test_bitrev.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
+        L.qpgpu_test_leaf_hash.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_two_to_one.argtypes = [u64p, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_fri_leaf_hash.argtypes = [u64p, u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
+        L.qpgpu_test_calib_colsum.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+        L.qpgpu_test_host_permute_ns.restype = ctypes.c_double
+        L.qpgpu_test_host_permute_ns.argtypes = [ctypes.c_int]
+        L.qpgpu_test_sync_roundtrip_us.restype = L.qpgpu_test_sync_roundtrip_us2.restype = ctypes.c_double
+        L.qpgpu_test_sync_roundtrip_us.argtypes = [ctypes.c_int]
+        L.qpgpu_test_sync_roundtrip_us2.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.qpgpu_bench_permute.restype = L.qpgpu_bench_lde.restype = ctypes.c_double
+        L.qpgpu_bench_permute.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        L.qpgpu_bench_lde.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -95,3 +130,167 @@ def synth_lib():
 def check(rc):
     if rc != 0:
         raise QpgpuError(rc, lib().qpgpu_last_error().decode())
+
+
+# short aliases used by tests/ and bench.py
+qpgpu = lib
+synth = synth_lib
+gpu_check = check
+
+
+class SynthCircuit:
+    """A synthetic circuit package + witness source (include/qpsynth.h)."""
+
+    def __init__(self, preset=None, **overrides):
+        S = synth()
+        self.params = SynthParams()
+        if preset is not None and S.qpsynth_preset(preset.encode(), ctypes.byref(self.params)) != 0:
+            raise ValueError(S.qpsynth_last_error().decode())
+        for k, v in overrides.items():
+            if k == "fri_arity_bits":
+                for i in range(8):
+                    self.params.fri_arity_bits[i] = v[i] if i < len(v) else 0
+                self.params.fri_num_layers = len(v)
+            elif k == "n_recursion":
+                for i, a in enumerate(v):
+                    self.params.n_recursion[i] = a
+            else:
+                setattr(self.params, k, v)
+        h = ctypes.c_void_p()
+        if S.qpsynth_circuit_create(ctypes.byref(self.params), ctypes.byref(h)) != 0:
+            raise ValueError(S.qpsynth_last_error().decode())
+        self.handle = h
+        self.desc = S.qpsynth_circuit_desc(h).contents
+        d = self.desc
+        self.n = 1 << d.degree_bits
+        self.N = self.n << d.fri_rate_bits
+        self.W = d.num_wires
+
+    def witness(self, seed):
+        wires = np.zeros((self.W, self.n), dtype=np.uint64)
+        pis = np.zeros(self.desc.num_public_inputs, dtype=np.uint64)
+        synth().qpsynth_witness(self.handle, seed, ptr(wires), ptr(pis))
+        return wires, pis
+
+    def salts(self, salt_seed):
+        out = np.zeros((3, 4, self.N), dtype=np.uint64)
+        synth().qpsynth_salts(self.handle, salt_seed, ptr(out))
+        return out
+
+    def constants_sigmas(self):
+        d = self.desc
+        S = d.num_constants + d.num_routed
+        return np.ctypeslib.as_array(d.constants_sigmas, shape=(S, self.n))
+
+    def __del__(self):
+        try:
+            synth().qpsynth_circuit_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class GpuCircuit:
+    """qpgpu_ctx + qpgpu_circuit: the product's resident circuit handle (include/qpgpu.h)."""
+
+    def __init__(self, desc, device=0):
+        L = qpgpu()
+        self.desc = desc
+        self.ctx = ctypes.c_void_p()
+        gpu_check(L.qpgpu_ctx_create(device, ctypes.byref(self.ctx)))
+        self.h = ctypes.c_void_p()
+        gpu_check(L.qpgpu_circuit_create(self.ctx, ctypes.byref(desc), ctypes.byref(self.h)))
+        self.proof_size = L.qpgpu_proof_size(self.h)
+
+    def cap(self):
+        out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
+        gpu_check(qpgpu().qpgpu_circuit_constants_sigmas_cap(self.h, ptr(out)))
+        return out
+
+    def prove(self, wires, pis, salts=None, salt_seed=0, pow_witness=None, wires_dev_ptr=None, stream=None):
+        L = qpgpu()
+        o = ProveOpts()
+        o.salts = ptr(salts) if salts is not None else None
+        o.salt_seed = salt_seed
+        o.have_pow_witness = 0 if pow_witness is None else 1
+        o.pow_witness = 0 if pow_witness is None else pow_witness
+        o.wires_on_device = 0 if wires_dev_ptr is None else 1
+        o.stream = stream
+        if wires_dev_ptr is None:
+            wires = np.ascontiguousarray(wires, dtype=np.uint64)
+            wp = wires.ctypes.data
+        else:
+            wp = wires_dev_ptr
+        buf = ctypes.create_string_buffer(self.proof_size)
+        n = ctypes.c_size_t()
+        gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
+        return ctypes.string_at(buf, n.value)          # one copy (buf.raw[:n] makes two)
+
+    def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False):
+        L = qpgpu()
+        b = len(pis_list)
+        o = ProveOpts()
+        o.salt_seed = salt_seed
+        o.wires_on_device = 1 if wires_on_device else 0
+        if wires_on_device:
+            wp = (ctypes.c_void_p * b)(*wires_list)
+        else:
+            wires_list = [np.ascontiguousarray(w, dtype=np.uint64) for w in wires_list]
+            wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in wires_list])
+        pp = (u64p * b)(*[ptr(p) for p in pis_list])
+        buf = ctypes.create_string_buffer(self.proof_size * b)
+        lens = (ctypes.c_size_t * b)()
+        gpu_check(L.qpgpu_prove_batch(self.h, b, wp, pp, len(pis_list[0]), ctypes.byref(o), buf, self.proof_size, lens))
+        return [ctypes.string_at(ctypes.addressof(buf) + i * self.proof_size, self.proof_size) for i in range(b)]
+
+    def stage_ms(self):
+        out = (ctypes.c_double * 16)()
+        k = qpgpu().qpgpu_last_stage_ms(out, 16)
+        return list(out[:k])
+
+    def close(self):
+        L = qpgpu()
+        if self.h:
+            L.qpgpu_circuit_destroy(self.h); self.h = None
+        if self.ctx:
+            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReferenceCircuitShape:
+    """CommonCircuitData + VerifierOnlyCircuitData of a reference artefact pair (common.bin / verifier.bin), parsed by the
+    product's own loaders (qpgpu_parse_common / qpgpu_parse_verifier_only). `desc` has no constants_sigmas (those live in prover.bin)."""
+
+    def __init__(self, common_bytes, verifier_only_bytes):
+        L = qpgpu()
+        self.desc = CircuitDesc()
+        self._gates = (Gate * 16)(); self._sel = (ctypes.c_uint32 * 16)(); self._grp = (ctypes.c_uint32 * 16)(); self._kis = (ctypes.c_uint64 * 160)()
+        gpu_check(L.qpgpu_parse_common(common_bytes, len(common_bytes), ctypes.byref(self.desc), self._gates, 16, self._sel, self._grp, 8, self._kis, 160))
+        cap = (ctypes.c_uint64 * (4 << 8))(); dig = (ctypes.c_uint64 * 4)()
+        ch = L.qpgpu_parse_verifier_only(verifier_only_bytes, len(verifier_only_bytes), cap, len(cap), dig)
+        if ch < 0:
+            raise RuntimeError(L.qpgpu_last_error().decode())
+        self.constants_sigmas_cap = np.array(cap[: 4 << ch], dtype=np.uint64).reshape(1 << ch, 4)
+        for i in range(4):
+            self.desc.circuit_digest[i] = dig[i]
+
+
+def replay_transcript(desc, proof):
+    """The product's Fiat-Shamir schedule over finished proof bytes (include/qpgpu_internal.h). Returns a dict of challenges."""
+    L = qpgpu()
+    out = (ctypes.c_uint64 * 256)()
+    k = L.qpgpu_replay_transcript(ctypes.byref(desc), proof, len(proof), out, 256)
+    if k < 0:
+        raise RuntimeError("qpgpu error %d: %s" % (k, L.qpgpu_last_error().decode()))
+    v = [int(x) for x in out[:k]]
+    nch = desc.num_challenges; o = 0
+    r = {}
+    for name, cnt in (("pi_hash", 4), ("betas", nch), ("gammas", nch), ("alphas", nch), ("zeta", 2), ("fri_alpha", 2),
+                      ("fri_betas", 2 * desc.fri_num_layers), ("pow_response", 1), ("query_indices", desc.fri_num_queries)):
+        r[name] = v[o:o + cnt]; o += cnt
+    assert o == k
+    return r
