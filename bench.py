@@ -191,7 +191,9 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes (if collected)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.preset, {}).get(dom)
+                tkey = args.preset if args.batch == 1 else "%s%d" % (args.preset, args.batch)
+                tj = json.load(open(tf))
+                traffic = tj.get(tkey, tj.get(args.preset, {})).get(dom)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
@@ -280,6 +282,21 @@ def main():
                     "tree_stage_s": round(tt, 4), "total_s": round(tl + tt, 4), "root_bytes": len(root.proof),
                     "note": "node witnesses from a pre-generated pool (stand-in for the Rust recursive-verifier witness generator); "
                             "device work of aggregate() only"}
+            # the reference's aggregator bench matrix (wormhole/aggregator/benches/aggregator.rs:107-130): aggregate() over b^d ready-made
+            # leaf proofs, (b, d) in {(2,1..5), (3..7,2)} — the same stand-in node circuit for every b (the real node circuit grows with b)
+            if dist is None:
+                matrix = []
+                for b_, d_ in [(2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]:
+                    cfg_ = agg.TreeAggregationConfig(b_, d_)
+                    lv = leaf_proofs[:cfg_.num_leaf_proofs]
+                    agg.aggregate_to_tree(lv, cfg_, np_)                               # warm
+                    torch.cuda.synchronize(); ta = time.perf_counter()
+                    for _ in range(3):
+                        agg.aggregate_to_tree(lv, cfg_, np_)
+                    torch.cuda.synchronize(); tb = (time.perf_counter() - ta) / 3
+                    matrix.append({"branching": b_, "depth": d_, "leaves": cfg_.num_leaf_proofs, "nodes": sum(b_ ** k for k in range(d_)),
+                                   "aggregate_ms": round(tb * 1e3, 3)})
+                tree["bench_matrix"] = matrix
             to_check += [("tree_leaf_first", leaf_proofs[0], 0, seeds[0]), ("tree_leaf_last", leaf_proofs[-1], (leaves_per_rank - 1) % nwit, seeds[0] + leaves_per_rank - 1)]
             tree_leaves, tree_root, tree_desc_owner = leaf_proofs, root.proof, scR
             gcR.close()

@@ -30,7 +30,7 @@ typedef enum qpgpu_status {
   QPGPU_ERR_BUFFER = -5,     /* output buffer too small */
   QPGPU_ERR_ZETA = -6,       /* zeta^n == 1 (upstream's "opening point is in the subgroup" exit) */
   QPGPU_ERR_POW = -7,        /* supplied pow_witness invalid, or grinding found nothing */
-  QPGPU_ERR_WITNESS = -8     /* non-canonical field element in an input */
+  QPGPU_ERR_WITNESS = -8     /* non-canonical field element (>= p) in the wire matrix, the public inputs or explicit salts */
 } qpgpu_status;
 
 /* Gate tags = qp-plonky2's default gate-serializer ids as they appear in CommonCircuitData
@@ -67,10 +67,17 @@ typedef struct qpgpu_circuit_desc {
 typedef struct qpgpu_ctx qpgpu_ctx;
 typedef struct qpgpu_circuit qpgpu_circuit;
 
+/* Zero-knowledge circuits need prover-side randomness for the 4 salt columns of each blinded oracle (qp-plonky2 draws
+ * F::rand_vec from OsRng). It is an INPUT here, in one of two forms:
+ *   salts     explicit [3 oracles][4][N] leaf-order columns of canonical field elements, or
+ *   salt_key  32 secret random bytes (from the OS RNG); the device expands them with the ChaCha8 keystream
+ *             (key = salt_key, nonce = salt_stream, block counter = element index / 8; csrc/salt.h), one-way in the key, so the
+ *             salts a FRI query opens say nothing about the unopened ones. Use a fresh key or a fresh salt_stream per proof.
+ * A zero-knowledge circuit with neither is refused with QPGPU_ERR_ARG; non-zk circuits ignore both. */
 typedef struct qpgpu_prove_opts {
-  const uint64_t* salts;      /* zk only: [3 oracles][4][N] leaf-order salt columns (prover-side randomness is an input,
-                                 SURVEY.md App. A.10); NULL => derive from salt_seed on the device */
-  uint64_t salt_seed;
+  const uint64_t* salts;
+  const uint8_t* salt_key;    /* [32] */
+  uint64_t salt_stream;
   uint64_t pow_witness;       /* used when have_pow_witness != 0; otherwise the smallest valid witness is ground */
   uint32_t have_pow_witness;
   uint32_t wires_on_device;   /* wires pointer(s) are device pointers (already resident in HBM) */
@@ -110,7 +117,7 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
 
 /* `batch` independent proofs of the same circuit, stream-pipelined on one GPU (BASELINE config #3; the unit the
  * aggregator shards per GPU, wormhole/aggregator/src/circuits/tree.rs:92-103). wires[i], public_inputs[i],
- * out + i*out_stride. opts->salt_seed / salts apply per proof as salt_seed + i / salts + i*3*4*N. */
+ * out + i*out_stride. opts->salt_stream / salts apply per proof as salt_stream + i / salts + i*3*4*N. */
 int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wires, const uint64_t* const* public_inputs,
                       size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride,
                       size_t* out_lens);

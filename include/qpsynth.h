@@ -37,8 +37,15 @@ void qpsynth_circuit_destroy(qpsynth_circuit* c);
 const qpgpu_circuit_desc* qpsynth_circuit_desc(const qpsynth_circuit* c);
 /* Full witness for proof index `seed`: wires [num_wires][n] column-major, public_inputs [16]. */
 int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, uint64_t* public_inputs);
-/* Salt columns exactly as the device derives them from opts.salt_seed: out [3][4][N]. */
-void qpsynth_salts(const qpsynth_circuit* c, uint64_t salt_seed, uint64_t* out);
+/* Salt columns exactly as the device derives them from (opts.salt_key, opts.salt_stream): out [3][4][N] — the ChaCha8 keystream of
+ * csrc/salt.h on the host (the oracle side of the parity tests gets its salts from here). */
+void qpsynth_salts_keyed(const qpsynth_circuit* c, const uint8_t* key32, uint64_t stream, uint64_t* out);
+/* The fixed PUBLIC key the tests and bench.py use with salt_stream = seed (a test convention: never a secret). */
+#define QPSYNTH_TEST_SALT_KEY_BYTES 0x51, 0x50, 0x2d, 0x74, 0x65, 0x73, 0x74, 0x2d, 0x73, 0x61, 0x6c, 0x74, 0x2d, 0x6b, 0x65, 0x79, \
+                                    0x00, 0x01, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b, 0x0c, 0x0d, 0x0e, 0x0f
+void qpsynth_salts(const qpsynth_circuit* c, uint64_t salt_seed, uint64_t* out);   /* = qpsynth_salts_keyed(test key, salt_seed) */
+/* One ChaCha8 block of the salt stream as eight field elements (known-answer tests of csrc/salt.h). */
+void qpsynth_salt_block(const uint8_t* key32, uint64_t nonce, uint64_t block, uint64_t* out8);
 const char* qpsynth_last_error(void);
 
 #ifdef __cplusplus

@@ -96,8 +96,15 @@ def test_aggregator_buffer_semantics():
     with pytest.raises(RuntimeError, match="no proofs to aggregate"):                       # aggregator.rs:75-77
         agg.aggregate()
     agg.push_proof(fake)                                                                    # buffer restarts (aggregator.rs:57-59)
-    res = agg.aggregate()
-    assert res.num_real == 1 and len(res.proofs) == 4                                       # padded with dummies (util.rs:11-29)
+    with pytest.raises(RuntimeError, match="failed to deserialize dummy proof"):            # no dummy available: never pad with a real leaf
+        agg.aggregate()
+    agg.push_proof(fake)
+    with pytest.raises(RuntimeError, match="failed to deserialize dummy proof"):            # a dummy of the wrong size does not fit
+        agg.aggregate(dummy_proof=pkg.ProofWithPublicInputs(bytes(8 * 17), 16))
+    agg.push_proof(fake)
+    dummy = pkg.ProofWithPublicInputs(bytes([1]) * (8 * 16), 16)
+    res = agg.aggregate(dummy_proof=dummy)
+    assert res.num_real == 1 and len(res.proofs) == 4 and res.proofs[1:] == [dummy] * 3     # padded with dummies (util.rs:11-29)
 
 
 def test_prover_commit_is_single_use_without_gpu():
@@ -155,3 +162,42 @@ def test_host_transcript_permutation_fast_form_equals_literal_form():
     assert [int(x) for x in z[:4]] == [0x3c18a9786cb0b359, 0xc4055e3364a246c3, 0x7953db0ab48808f4, 0xc71603f33a1144ca]
     s = np.arange(12, dtype=np.uint64); S.qpsynth_host_permute(ptr(s), 0)
     assert [int(x) for x in s[:4]] == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47, 0xd40285597c6a8825, 0x613a4f81e81231d2]
+
+
+def test_salt_stream_is_chacha8():
+    """csrc/salt.h: key-derived salts are the ChaCha8 keystream (DJB layout: 64-bit block counter, 64-bit nonce), eight u64 per block,
+    each taken mod p by one conditional subtraction. Known answer: the all-zero key/nonce/counter block of the ChaCha8 test vectors
+    (3e00ef2f 895f40d6 ...), and a pure-Python restatement on random inputs."""
+    import random, struct
+    S = synth()
+    out = np.zeros(8, dtype=np.uint64)
+    S.qpsynth_salt_block(bytes(32), 0, 0, ptr(out))
+    ks = bytes.fromhex("3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42")
+    want = [z - P if z >= P else z for z in struct.unpack("<8Q", ks)]
+    assert [int(x) for x in out] == want
+
+    def rotl(x, r): return ((x << r) | (x >> (32 - r))) & 0xffffffff
+    def qr(x, a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 16); x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 8); x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 7)
+    def block(key, nonce, ctr):
+        s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + list(struct.unpack("<8I", key)) + [ctr & 0xffffffff, ctr >> 32, nonce & 0xffffffff, nonce >> 32]
+        x = s[:]
+        for _ in range(4):
+            qr(x, 0, 4, 8, 12); qr(x, 1, 5, 9, 13); qr(x, 2, 6, 10, 14); qr(x, 3, 7, 11, 15)
+            qr(x, 0, 5, 10, 15); qr(x, 1, 6, 11, 12); qr(x, 2, 7, 8, 13); qr(x, 3, 4, 9, 14)
+        w = [(a + b) & 0xffffffff for a, b in zip(x, s)]
+        return [(lambda z: z - P if z >= P else z)(w[2 * i] | (w[2 * i + 1] << 32)) for i in range(8)]
+    rnd = random.Random(5)
+    for _ in range(50):
+        key = bytes(rnd.randrange(256) for _ in range(32)); nonce = rnd.randrange(1 << 64); ctr = rnd.randrange(1 << 40)
+        S.qpsynth_salt_block(key, nonce, ctr, ptr(out))
+        assert [int(x) for x in out] == block(key, nonce, ctr)
+    # column layout: element (oracle*4 + column)*N + leaf is word (index % 8) of block index // 8
+    sc = SynthCircuit("TZ")
+    salts = sc.salts_keyed(bytes(range(32)), 9)
+    flat = salts.reshape(-1)
+    for idx in (0, 7, 8, 12345 % flat.size, flat.size - 1):
+        S.qpsynth_salt_block(bytes(range(32)), 9, idx // 8, ptr(out))
+        assert int(flat[idx]) == int(out[idx % 8])
+    assert np.array_equal(sc.salts(9), sc.salts_keyed(TEST_SALT_KEY, 9)) and int(flat.max()) < P

@@ -108,3 +108,47 @@ def test_gloo_world2_distributed_tree_matches_single_process(tmp_path):
                         "--master-port", "29612", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_gloo_world8_distributed_tree_schedule(tmp_path):
+    """The 8-rank schedule of BASELINE configs[3] (512 leaves: 64 per rank, branching 2) and its small relatives, on gloo: levels are
+    local while a rank's run holds whole chunks, then one gather per level; every rank must return the single-process root. A batching
+    prover (prove_chunks) must be handed this rank's chunks of a top level as one batch too."""
+    script = tmp_path / "t8.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        agg = importlib.import_module("zk-circuits_amd.aggregator")
+    """ % ROOT) + _fake_chunk_prover_src() + textwrap.dedent("""
+        class Batched:
+            def __init__(self): self.calls = []
+            def prove_chunks(self, chunks, level):
+                self.calls.append((level, len(chunks))); return [chunk_prover(c, level) for c in chunks]
+            def __call__(self, chunk, level):
+                self.calls.append((level, -1)); return chunk_prover(chunk, level)
+        for b, depth in ((2, 3), (2, 6), (2, 9), (4, 3), (8, 1)):          # 1, 8, 64 leaves per rank at branching 2; 512 = configs[3]
+            cfg = agg.TreeAggregationConfig(b, depth)
+            n = cfg.num_leaf_proofs
+            leaves = [bytes([i % 251, i // 251]) * 100 for i in range(n)]
+            per = n // world
+            bp = Batched()
+            root = agg.aggregate_to_tree_distributed(leaves[rank * per:(rank + 1) * per], cfg, bp, size_of)
+            want = agg.aggregate_to_tree(leaves, cfg, chunk_prover)
+            assert root.proof == want.proof, (b, depth, rank)
+            assert all(k != -1 for _, k in bp.calls), bp.calls               # never chunk by chunk when the prover can batch
+            if (b, depth) == (2, 9):                                          # 64 leaves per rank: six local levels, then 4 / 2 / 1 chunks dealt to ranks 0..
+                local = [c for c in bp.calls if c[0] < 6]
+                assert local == [(l, 32 >> l) for l in range(6)], bp.calls
+                top = [c for c in bp.calls if c[0] >= 6]
+                assert top == ([(6, 1)] if rank < 4 else []) + ([(7, 1)] if rank < 2 else []) + ([(8, 1)] if rank < 1 else []), (rank, bp.calls)
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 8

@@ -93,6 +93,81 @@ def test_bad_arguments(circuits):
         gc.prove(wires, bad)
 
 
+def test_non_canonical_wire_or_salt_is_rejected_and_the_handle_stays_usable(circuits):
+    """include/qpgpu.h promises QPGPU_ERR_WITNESS for any input element >= p: a wire of exactly p (or p + 5) would otherwise flow
+    through the lazy arithmetic and be copied raw into the query rows, giving bytes the reference cannot produce with rc 0."""
+    for preset in ("T", "TZ"):
+        sc, oc, gc = circuits(preset)
+        wires, pis = sc.witness(11)
+        zk = bool(sc.desc.zero_knowledge)
+        want = oc.prove(wires, pis, sc.salts(11) if zk else None)
+        for col, row, val in ((0, 0, P), (sc.W - 1, sc.n - 1, P + 5), (37, 5, 0xFFFFFFFFFFFFFFFF)):
+            bad = wires.copy(); bad[col, row] = val
+            with pytest.raises(RuntimeError, match="error -8.*non-canonical"):
+                gc.prove(bad, pis, salt_seed=11)
+            with pytest.raises(RuntimeError, match="error -8.*non-canonical"):
+                gc.prove_batch([wires, bad, wires], [pis, pis, pis], salt_seed=11)
+        if zk:
+            salts = sc.salts(11).copy(); salts[2, 3, sc.N - 1] = P
+            with pytest.raises(RuntimeError, match="error -8.*non-canonical"):
+                gc.prove(wires, pis, salts=salts)
+        assert gc.prove(wires, pis, salt_seed=11) == want               # the recycled workspace is clean again
+        assert gc.prove_batch([wires] * 3, [pis] * 3, salt_seed=11)[0] == want
+
+
+def test_zero_knowledge_needs_salts_or_a_key(circuits):
+    """Prover-side randomness is an input (qp-plonky2 draws it from OsRng): a zk circuit refuses to prove without explicit salts
+    or a 32-byte key; the key-derived salts are the ChaCha8 keystream the synthetic generator restates on the host."""
+    sc, oc, gc = circuits("TZ")
+    wires, pis = sc.witness(5)
+    with pytest.raises(RuntimeError, match="error -1.*salt_key"):
+        gc.prove(wires, pis, salt_key=None)
+    with pytest.raises(RuntimeError, match="error -1.*salt_key"):
+        gc.prove_batch([wires], [pis], salt_key=None)
+    key = bytes(range(100, 132))
+    got = gc.prove(wires, pis, salt_seed=77, salt_key=key)
+    assert got == oc.prove(wires, pis, sc.salts_keyed(key, 77)) and oc.verify(got) is None
+    assert got != gc.prove(wires, pis, salt_seed=78, salt_key=key)           # another stream, other salts
+    assert got != gc.prove(wires, pis, salt_seed=77, salt_key=bytes(32))     # another key
+    batch = gc.prove_batch([wires, wires], [pis, pis], salt_seed=76, salt_key=key)   # proof i uses stream 76 + i
+    assert batch[1] == got
+    nz, noc, ngc = circuits("T")                                             # non-zk circuits ignore both
+    w, p = nz.witness(5)
+    assert ngc.prove(w, p, salt_key=None) == noc.prove(w, p)
+
+
+@pytest.mark.parametrize("shape", [dict(degree_bits=13, fri_arity_bits=[]), dict(degree_bits=9, fri_cap_height=12, fri_arity_bits=[])])
+def test_large_handoffs_fit_the_pinned_buffer(shape):
+    """The device->host hand-off buffer is sized for the largest fetch: a 2^13-coefficient final polynomial (no FRI reduction) and a
+    4096-digest cap (cap height 12) both used to exceed the old fixed-size estimate."""
+    sc = SynthCircuit("T", **shape); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+    try:
+        w, p = sc.witness(3)
+        got = gc.prove(w, p)
+        assert first_diff(got, oc.prove(w, p)) is None and oc.verify(got) is None
+    finally:
+        gc.close()
+
+
+def test_handoff_wait_modes_give_the_same_bytes(monkeypatch):
+    """QPGPU_HANDOFF_SPIN_US=0 naps between polls from the start (what batch workers fall back to on a busy host), QPGPU_NO_PUBLISH=1
+    uses copy + stream synchronise; the knobs are read when a context is created (csrc/options.h)."""
+    sc = SynthCircuit("TZ"); oc = OracleCircuit(sc.desc)
+    w, p = sc.witness(8); want = oc.prove(w, p, sc.salts(8))
+    for env in ({"QPGPU_HANDOFF_SPIN_US": "0"}, {"QPGPU_NO_PUBLISH": "1"}, {"QPGPU_STREAMS": "2", "QPGPU_HANDOFF_SPIN_US": "5"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gc = GpuCircuit(sc.desc)
+        try:
+            assert gc.prove(w, p, salt_seed=8) == want
+            assert gc.prove_batch([w] * 5, [p] * 5, salt_seed=8)[0] == want
+        finally:
+            gc.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    GpuCircuit(sc.desc).close()                                   # back to the defaults for the tests that follow
+
+
 def test_concurrent_proves_are_reentrant(circuits):
     """qpgpu_prove from several host threads on one shared circuit handle (the aggregator's rayon workers do this in the
     reference, wormhole/aggregator/src/circuits/tree.rs:100): each call gets its own stream + workspace."""

@@ -173,3 +173,13 @@ def test_oracle_proofs_match_the_committed_self_check_digests(key):
     want = _selfcheck()[key]
     assert len(pf) == want["len"] and hashlib.sha256(pf).hexdigest() == want["sha256"]
     assert hashlib.sha256(oc.cap().tobytes()).hexdigest() == want["cap_sha256"]
+
+
+def test_oracle_and_synth_under_sanitizers():
+    """`make -C oracle asan`: the checker and the synthetic generator rebuilt with AddressSanitizer + UBSan and driven by
+    oracle/selftest.cc (golden proof verification, malformed-input rejection, prove/verify/tamper on T, TZ and RT). Host code only —
+    GPU ASan is not available on this pool."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

@@ -36,11 +36,13 @@ def per_kernel(rows, counter):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--preset", default="B"); args = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--preset", default="B"); ap.add_argument("--batch", type=int, default=1); args = ap.parse_args()
     out = {}
     calib_w, calib_n = 139, 1 << 17
     calib_cmd = ["python3", "-c", "import ctypes; L=ctypes.CDLL('zk-circuits_amd/libqpgpu.so'); L.qpgpu_test_calib_colsum.argtypes=[ctypes.c_int,ctypes.c_size_t,ctypes.c_int]; L.qpgpu_test_calib_colsum(%d,%d,5)" % (calib_w, calib_n)]
-    bench_cmd = ["python3", "bench.py", "--preset", args.preset, "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    # one workload per profiler run: no aggregation-tree / pipelined extras, so every counter row belongs to this preset's proofs
+    bench_cmd = ["python3", "bench.py", "--preset", args.preset, "--steps", "3" if args.preset == "V" else "4", "--warmup", "1", "--no-cpu-baseline",
+                 "--no-tree", "--no-pipelined"] + (["--batch", str(args.batch)] if args.batch > 1 else [])
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         c = per_kernel(run_pmc(counter, "gpurun_out/pmc_calib_" + counter, calib_cmd), counter)
@@ -60,11 +62,13 @@ def main():
                       "raw_fetch_KiB": avg, "raw_write_KiB": w}
     leaf = [k for k in kernels if "k_leaves_colmajor" in k]
     traffic = None
-    if leaf:
-        kk = kernels[leaf[0]]; traffic = kk["fetch_bytes"] + kk["write_bytes"]
+    if leaf:                                   # per launch, averaged over the launches of every form of the leaf kernel (plain / fused levels)
+        n = sum(kernels[k]["launches"] for k in leaf)
+        traffic = sum((kernels[k]["fetch_bytes"] + kernels[k]["write_bytes"]) * kernels[k]["launches"] for k in leaf) / n
     path = os.path.join(ROOT, "profiles", "traffic.json")
     allj = json.load(open(path)) if os.path.exists(path) else {}
-    allj[args.preset] = {"merkle_leaves_colmajor": traffic, "detail": detail, "kernels": kernels}
+    key = args.preset if args.batch == 1 else "%s%d" % (args.preset, args.batch)
+    allj[key] = {"merkle_leaves_colmajor": traffic, "detail": detail, "kernels": kernels}
     json.dump(allj, open(path, "w"), indent=1)
     print(json.dumps({"preset": args.preset, "merkle_leaves_colmajor_bytes_per_launch": traffic, "calibration": detail["calibration"]}, indent=1))
 

@@ -9,6 +9,7 @@ CircuitBuilder / generators on the host (tree.rs:106-135), which this image cann
 gathered, padded leaf set — exactly what `aggregate_level` (tree.rs:92-103) consumes — rather than a root proof.
 """
 import ctypes
+import os
 import numpy as np
 from . import ffi
 from .prover import ProofWithPublicInputs
@@ -52,15 +53,21 @@ class WormholeProofAggregator:
             raise RuntimeError("tried to add proof when proof buffer is full")
         self.proofs_buffer.append(proof)
 
-    def prove_leaves(self, circuit_inputs_list, salt_seed=0):
-        """Proves independent leaf witnesses as one stream-pipelined batch on this GPU (qpgpu_prove_batch) and pushes them."""
+    def prove_leaves(self, circuit_inputs_list, salt_seed=None, salt_key=None):
+        """Proves independent leaf witnesses as one stream-pipelined batch on this GPU (qpgpu_prove_batch) and pushes them.
+        Salts: ChaCha8(salt_key, stream i) for leaf i with a fresh OS-RNG key per call, unless `salt_seed` is given (tests: the
+        public test key with stream salt_seed + i, reproducible by the oracle)."""
         cd = self.leaf_circuit_data
         ws, ps = zip(*[cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs) for ci in circuit_inputs_list])
         b = len(ws)
         wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in ws])
         pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for p in ps])
         o = ffi.ProveOpts()
-        o.salt_seed = salt_seed
+        if salt_seed is not None:
+            key, o.salt_stream = ffi.TEST_SALT_KEY, salt_seed
+        else:
+            key, o.salt_stream = (salt_key or os.urandom(32)), 0
+        keep = ffi.set_salt_key(o, key)      # noqa: F841
         buf = ctypes.create_string_buffer(cd.proof_size * b)
         lens = (ctypes.c_size_t * b)()
         ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf,
@@ -78,10 +85,14 @@ class WormholeProofAggregator:
             raise RuntimeError("proofs to aggregate was more than the maximum allowed")
         num_real = len(proofs)
         if num_real < self.config.num_leaf_proofs:
+            # util.rs:11-29: pad with THE dummy proof of the leaf circuit (never with a real leaf: that would repeat its nullifier and
+            # amounts in the aggregated public inputs), and fail if there is none or it does not fit
             if dummy_proof is None:
-                if not proofs:
+                if self.leaf_circuit_data is None:
                     raise RuntimeError("failed to deserialize dummy proof")
-                dummy_proof = proofs[0]
+                dummy_proof = self.leaf_circuit_data.dummy_proof()
+            if proofs and len(dummy_proof) != len(proofs[0]):
+                raise RuntimeError("failed to deserialize dummy proof: %d bytes, leaf proofs have %d" % (len(dummy_proof), len(proofs[0])))
             proofs = proofs + [dummy_proof] * (self.config.num_leaf_proofs - num_real)
         if chunk_prover is not None:
             return aggregate_to_tree(proofs, self.config, chunk_prover)
@@ -165,7 +176,11 @@ def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof
             else:
                 everything = proofs                                     # already replicated on every rank
             chunks = [everything[i:i + b] for i in range(0, len(everything), b)]
-            mine = [chunk_prover(c, level).proof for i, c in enumerate(chunks) if i % world == rank]
+            my_chunks = [c for i, c in enumerate(chunks) if i % world == rank]
+            if hasattr(chunk_prover, "prove_chunks") and my_chunks:      # a device prover batches this rank's chunks of the level
+                mine = [p.proof for p in chunk_prover.prove_chunks(my_chunks, level)]
+            else:
+                mine = [chunk_prover(c, level).proof for c in my_chunks]
             # one parent per chunk; parents are gathered back in chunk order (rank i % world proved chunk i)
             per_rank = (len(chunks) + world - 1) // world
             size = proof_size_of_level(level + 1)

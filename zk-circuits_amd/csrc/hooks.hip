@@ -6,6 +6,7 @@
 #include <string>
 #include <chrono>
 #include "poseidon.h"
+#include "salt.h"
 
 namespace qp { extern thread_local std::string g_last_error; int set_err(int code, const std::string& m); }
 using namespace qp;
@@ -123,15 +124,15 @@ double qpgpu_test_sync_roundtrip_us2(int iters, int mode) {
   u64* pin_dev = nullptr; (void)hipHostGetDevicePointer((void**)&pin_dev, pin, 0);
   hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  salt_fill(d.u(), 16, 1, 0, s); (void)hipStreamSynchronize(s);
+  salt_fill(d.u(), 16, SaltKey{{1, 2, 3, 4, 5, 6, 7, 8}}, 1, 0, s); (void)hipStreamSynchronize(s);
   auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; i++) {
     if (mode == 3) {
       volatile u64* flag = pin + 64; *flag = 0;
-      salt_fill(pin_dev, 17, (u64)i + 1, 0, s);            // writes 68 u64 incl. slot 64 (non-zero with overwhelming probability)
+      salt_fill(pin_dev, 18, SaltKey{{1, 2, 3, 4, 5, 6, 7, 8}}, (u64)i + 1, 0, s);   // writes 72 u64 incl. slot 64 (non-zero with overwhelming probability)
       while (*flag == 0) { }
     } else {
-      salt_fill(d.u(), 16, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s);
+      salt_fill(d.u(), 16, SaltKey{{1, 2, 3, 4, 5, 6, 7, 8}}, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s);
       if (mode == 0) (void)hipStreamSynchronize(s);
       else if (mode == 1) { while (hipStreamQuery(s) == hipErrorNotReady) { } }
       else { (void)hipEventRecord(ev, s); while (hipEventQuery(ev) == hipErrorNotReady) { } }
@@ -146,9 +147,9 @@ double qpgpu_test_sync_roundtrip_us(int iters) {
   DevBuf d; if (d.alloc(4096) != hipSuccess) return -1;
   u64* pin = nullptr; if (hipHostMalloc((void**)&pin, 4096, hipHostMallocDefault) != hipSuccess) return -1;
   hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-  salt_fill(d.u(), 16, 1, 0, s); (void)hipStreamSynchronize(s);
+  salt_fill(d.u(), 16, SaltKey{{1, 2, 3, 4, 5, 6, 7, 8}}, 1, 0, s); (void)hipStreamSynchronize(s);
   auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iters; i++) { salt_fill(d.u(), 16, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
+  for (int i = 0; i < iters; i++) { salt_fill(d.u(), 16, SaltKey{{1, 2, 3, 4, 5, 6, 7, 8}}, 1, 0, s); (void)hipMemcpyAsync(pin, d.p, 512, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
   auto t1 = std::chrono::steady_clock::now();
   (void)hipStreamDestroy(s); (void)hipHostFree(pin);
   return std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;

@@ -4,21 +4,37 @@
 #include "kernels.h"
 #include "poseidon_dev.h"
 #include "salt.h"
+#include "options.h"
 #include <cstdlib>
 
 namespace qp {
 
-__global__ void k_salt_fill(u64* cols, size_t N, u64 seed, int oracle) {
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i < 4 * N) cols[i] = salt_value(seed, (u64)oracle * 4 * N + i);
+// one ChaCha8 block (eight salts) per thread
+__global__ void k_salt_fill(u64* cols, size_t N, SaltKey key, u64 nonce, int oracle) {
+  size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b >= N / 2) return;                                   // 4N elements = N/2 blocks
+  u64 o[8]; salt_block(key, nonce, (u64)oracle * (N / 2) + b, o);
+#pragma unroll
+  for (int k = 0; k < 8; k++) cols[b * 8 + k] = o[k];
 }
-void salt_fill(u64* cols, size_t N, u64 seed, int oracle, hipStream_t s) {
-  hipLaunchKernelGGL(k_salt_fill, dim3((unsigned)((4 * N + 255) / 256)), dim3(256), 0, s, cols, N, seed, oracle);
+void salt_fill(u64* cols, size_t N, const SaltKey& key, u64 nonce, int oracle, hipStream_t s) {
+  hipLaunchKernelGGL(k_salt_fill, dim3((unsigned)((N / 2 + 255) / 256)), dim3(256), 0, s, cols, N, key, nonce, oracle);
+}
+__global__ void __launch_bounds__(256) k_check_canonical(const u64* data, size_t count, u64* flag) {
+  bool bad = false;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) bad |= data[i] >= GL_P;
+  if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)flag, 1ULL);
+}
+void check_canonical(const u64* data, size_t count, u64* flag, hipStream_t s) {
+  if (!count) return;
+  size_t blocks = (count + 256 * 8 - 1) / (256 * 8); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_check_canonical, dim3((unsigned)blocks), dim3(256), 0, s, data, count, flag);
 }
 
-__global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq) {
+__global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq, const u64* extra) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  if (extra && blockIdx.x == 0 && threadIdx.x == 0) dst[words] = *extra;
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -31,9 +47,9 @@ __global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_
     if (last) { __threadfence_system(); *(volatile u64*)flag = seq; }
   }
 }
-void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s) {
+void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s, const u64* extra) {
   unsigned blocks = (unsigned)((words + 2047) / 2048); if (blocks < 1) blocks = 1; if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq);
+  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq, extra);
 }
 
 __global__ void k_permute_batch(u64* states, size_t count) {
@@ -188,7 +204,7 @@ int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t
   // Measured (MI355X, 2^17 leaves): the pair form hashes leaves 9 % SLOWER than one permutation per lane (its per-lane stream is
   // not half: DPP moves, parity-selected constants and the one-sided partial rounds add ~20 % work), so it is only used for the
   // latency-bound tree levels below; QPGPU_PAIR_LEAVES=1 switches it on here for experiments.
-  static const bool pair_leaves = [] { const char* v = getenv("QPGPU_PAIR_LEAVES"); return v && v[0] == '1'; }();
+  const bool pair_leaves = opts().pair_leaves != 0;
   if (pair_leaves && num_leaves <= PAIR_MAX_LEAVES && num_leaves >= 2) {
     hipLaunchKernelGGL(k_leaves_colmajor_pair, dim3((unsigned)((2 * num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
     return 0;
@@ -271,7 +287,6 @@ __global__ void __launch_bounds__(64) k_level_coop(const u64* in, u64* out, size
 // A ~12 us level costs ~4 us of dispatch/drain as its own kernel, so the 11 small levels of a 2^17-leaf tree go from 11 launches
 // to 2. The permutation's lane exchange is wave-local (COOP_SYNC), so only the level hand-off needs workgroup barriers, and waves
 // whose groups have all retired skip the permutation.
-static int getenv_int_m(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
 template <int G>
 __global__ void __launch_bounds__(16 * G) k_levels_coop_fused(const u64* __restrict__ in, u64* __restrict__ out, size_t parents0, int nlev) {
   __builtin_amdgcn_s_setprio(3);
@@ -303,7 +318,7 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
   // batches are VALU-bound, yet per-lane levels down to 4 K parents measured 341-344 vs 356-369 proofs/s (medians of 9 batches
   // of 48, four worker streams): the longer critical path of every proof costs more overlap than the saved instructions buy.
   (void)batch;
-  static const int env_pair = getenv_int_m("QPGPU_PAIR_MAX", -1), env_coop = getenv_int_m("QPGPU_COOP_MAX", -1);   // tuning overrides
+  const int env_pair = opts().pair_max, env_coop = opts().coop_max;   // tuning overrides
   const size_t pair_max = env_pair >= 0 ? (size_t)env_pair : PAIR_MAX_LEAVES;
   const size_t coop_max = env_coop >= 0 ? (size_t)env_coop : COOP_MAX_PARENTS;
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
@@ -314,7 +329,7 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
     else if (parents > coop_max) hipLaunchKernelGGL(k_level_pair, dim3((unsigned)((2 * parents + 255) / 256)), dim3(256), 0, s, cur, out, parents);
     else {
       // latency-bound tail: climb up to 6 levels per launch
-      static const int fuse = getenv_int_m("QPGPU_FUSE_LEVELS", 1);
+      const int fuse = opts().fuse_levels;
       int nlev = 0; { size_t c2 = cnt; while (c2 > cap && nlev < 6) { c2 >>= 1; nlev++; } }
       if (fuse && nlev >= 2 && parents >= 32) {
         hipLaunchKernelGGL(k_levels_coop_fused<32>, dim3((unsigned)((parents + 31) / 32)), dim3(512), 0, s, cur, out, parents, nlev);

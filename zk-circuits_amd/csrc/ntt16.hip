@@ -10,6 +10,7 @@
 // x8 coset LDE (prescale fused into the load). Larger transforms (quotient iNTT at 2^17, the 2^20 stress config) stay on
 // the tiled multi-pass kernel in ntt.hip. Rows a3/a4 of SURVEY.md §8.
 #include "kernels.h"
+#include "options.h"
 #include "poseidon_dev.h"
 #include <cstdlib>
 
@@ -251,19 +252,17 @@ __global__ void __launch_bounds__(256) k_ntt_strided8(StridedArgs a) {
 }
 
 bool ntt16_supported(int log_n) {
-  static const int disabled = [] { const char* v = getenv("QPGPU_NTT16"); return v && v[0] == '0'; }();   // A/B switch for experiments
+  const int mode = opts().ntt16;   // 0 off, 1 default, 2 forced up to 2^14 (A/B switch for experiments)
   // Measured on MI355X (profiles/r01 notes): at 2^13/2^14 the 64-139 KB LDS image allows one or two workgroups per CU, which
   // gains nothing for a single proof (5.18 vs 5.14 ms) and costs 12 % of stream-pipelined throughput (240 vs 273 proofs/s)
   // because it evicts co-resident kernels of other proofs. Up to 2^12 (35 KB, 256 threads) it is 1.6-1.8x faster than the
   // tiled kernel, so that is where it is used (FRI layers, small circuits); QPGPU_NTT16=2 forces it up to 2^14.
-  static const int force = [] { const char* v = getenv("QPGPU_NTT16"); return v && v[0] == '2'; }();
-  return !disabled && log_n >= 9 && log_n <= (force ? 14 : 12);
+  return mode != 0 && log_n >= 9 && log_n <= (mode == 2 ? 14 : 12);
 }
 
 // Forward LDE for 2^13 <= n <= 2^24: strided passes down to a 2^9..2^12 block size, then k_ntt16 on the contiguous blocks.
 bool lde_strided_supported(int log_n) {
-  static const bool disabled = [] { const char* v = getenv("QPGPU_NTT_STRIDED"); return v && v[0] == '0'; }();
-  return !disabled && log_n >= 13 && log_n <= 24;
+  return opts().ntt_strided != 0 && log_n >= 13 && log_n <= 24;
 }
 void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, const u64* pre,
                      const NttPlan& pl, hipStream_t s, bool inverse) {
@@ -274,7 +273,7 @@ void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_strid
   const size_t n = size_t(1) << log_n; const unsigned transforms = (unsigned)(count << log_cosets);
   int rem = log_n; bool first = true;
   while (rem > 12) {
-    static const int use_m8 = [] { const char* v = getenv("QPGPU_NTT_M8"); return v ? atoi(v) : 1; }();
+    const int use_m8 = opts().ntt_m8;
     int M = rem - 12 <= 4 ? rem - 12 : (rem - 9 < 8 ? rem - 9 : 8);
     if (M > 4 && (M < 8 || !use_m8)) M = 4;          // only M <= 4 (registers) and M = 8 (one LDS exchange) exist
     a.b_lo = rem - M; a.first = first ? 1 : 0;

@@ -8,6 +8,8 @@
 // stages, exactly where upstream's Challenger runs; each challenge costs one small D2H copy of a cap / opening set.
 #include "../../include/qpgpu_internal.h"
 #include "kernels.h"
+#include "options.h"
+#include "salt.h"
 #include "poseidon.h"
 #include <string>
 #include <vector>
@@ -17,10 +19,31 @@
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
+#include <memory>
+#include <chrono>
+#include <time.h>
 
 namespace qp {
 thread_local std::string g_last_error;
 int set_err(int code, const std::string& m) { g_last_error = m; return code; }
+
+// ---- options (options.h): the one place that reads the environment
+static Options g_opts;
+const Options& opts() { return g_opts; }
+void options_refresh_from_env() {
+  Options o;
+  auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
+  o.streams = geti("QPGPU_STREAMS", o.streams); o.handoff_spin_us = geti("QPGPU_HANDOFF_SPIN_US", o.handoff_spin_us);
+  o.no_publish = geti("QPGPU_NO_PUBLISH", o.no_publish); o.timing = geti("QPGPU_TIMING", o.timing);
+  o.split_quotient = geti("QPGPU_SPLIT_QUOTIENT", o.split_quotient); o.split_fork_late = geti("QPGPU_SPLIT_FORK_LATE", o.split_fork_late);
+  o.split_serial = geti("QPGPU_SPLIT_SERIAL", o.split_serial); o.quotient_halves = geti("QPGPU_QUOTIENT_HALVES", o.quotient_halves);
+  o.shared_mode = geti("QPGPU_SHARED_MODE", o.shared_mode); o.l0_table = geti("QPGPU_L0_TABLE", o.l0_table);
+  o.pair_leaves = geti("QPGPU_PAIR_LEAVES", o.pair_leaves); o.pair_max = geti("QPGPU_PAIR_MAX", o.pair_max); o.coop_max = geti("QPGPU_COOP_MAX", o.coop_max);
+  o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
+  o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
+  g_opts = o;
+}
+namespace { struct OptionsInit { OptionsInit() { options_refresh_from_env(); } } g_options_init; }
 }
 using namespace qp;
 
@@ -86,10 +109,10 @@ struct Workspace {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_gates = nullptr, ev_perm = nullptr;   // off-critical-path quotient parts
   u64 *q_gate_terms = nullptr, *q_perm_terms = nullptr;
   u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
-  u64* pub_counter = nullptr;  // device counter used by multi-block publishes (only ever incremented: tested modulo the grid)
+  u64* pub_counter = nullptr;  // device counter of multi-block publishes: the last block to arrive resets it (k_publish)
   u64 pub_seq = 0;
   bool shared_gpu = false;    // opt-in (QPGPU_SHARED_MODE=1): kernel choices that assume other proofs fill the chip
-  bool pow_armed = false;     // pow_result holds ~0 (re-armed by the last proof's gather kernel)
+  bool pow_armed = false;     // pow_result[0] holds ~0 and pow_result[1] (the non-canonical-input flag) 0: re-armed by the last proof's gather kernel
   bool batch_mode = false;    // set for workers of qpgpu_prove_batch when several proofs share the chip: fused quotient kernel
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
@@ -137,7 +160,6 @@ static void prof_flush(Workspace* w) {   // call after the stream has been synch
   w->pev_used = 0;
 }
 
-static int getenv_int(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
 
 // ------------------------------------------------------------------------------------------------ workspace
 static size_t plan_workspace(qpgpu_circuit* c, Workspace* w) {
@@ -188,7 +210,10 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
       ws_destroy(w); return set_err(QPGPU_ERR_HIP, "side stream / event creation failed");
     }
   }
-  w->pinned_elems = 4096 + 2 * c->lay.n_openings + (c->lay.bytes_per_query * c->d.fri_num_queries) / 8 + 64;
+  // the largest thing fetch_to_host ever brings over: a cap, the opening set, the final polynomial, the serialized query rounds (+1 extra word)
+  { size_t m = (size_t(4) << c->cap_h) + 1;
+    m = std::max(m, 2 * c->lay.n_openings); m = std::max(m, 2 * c->lay.final_poly_len);
+    m = std::max(m, (c->lay.bytes_per_query * c->d.fri_num_queries + 7) / 8); w->pinned_elems = m + 64; }
   e = hipHostMalloc((void**)&w->pinned, (w->pinned_elems + 8) * 8, hipHostMallocMapped);
   if (e != hipSuccess) { (void)hipStreamDestroy(w->stream); (void)hipFree(w->arena.base); delete w; return set_err(QPGPU_ERR_OOM, "hipHostMalloc failed"); }
   if (hipHostGetDevicePointer((void**)&w->pinned_dev, w->pinned, 0) != hipSuccess) w->pinned_dev = nullptr;
@@ -210,24 +235,39 @@ static void ws_destroy(Workspace* w) {
 
 // Brings `words` u64 from device memory to w->pinned and waits for them. Fast path: publish kernel + spin on the mapped flag;
 // fallback (no mapped pointer, or the flag does not arrive): copy + stream synchronise, which also surfaces kernel faults.
-static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t words) {
-  if (w->pinned_dev && getenv_int("QPGPU_NO_PUBLISH", 0) == 0) {
+// `extra` (optional) is one more device word, delivered at w->pinned[words].
+// The wait is adaptive: busy-poll the flag for the spin budget (Options::handoff_spin_us; a hand-off usually lands within it), then nap
+// 20 us between polls so that a stage that runs for a millisecond (the wires leaf hash) does not pin a host core, which matters
+// with 4 worker streams x 8 ranks on one host. Every hand-off also surfaces launch errors of the stage it ends (hipGetLastError).
+static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t words, const u64* extra = nullptr) {
+  if (words + (extra ? 1 : 0) > w->pinned_elems) return set_err(QPGPU_ERR_BUFFER, "internal: hand-off larger than the pinned buffer");
+  { hipError_t le = hipGetLastError(); if (le != hipSuccess) return set_err(QPGPU_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le)); }
+  if (w->pinned_dev && !opts().no_publish) {
     const u64 seq = ++w->pub_seq;
     volatile u64* flag = w->pinned + w->pinned_elems;
-    publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s);
+    publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s, extra);
+    const int budget_us = opts().handoff_spin_us >= 0 ? opts().handoff_spin_us : (w->batch_mode ? 50 : 2000);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool napping = false; uint64_t naps = 0;
     for (uint64_t spins = 0;; spins++) {
       if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+      if (!napping) {
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+        __builtin_ia32_pause();
 #endif
-      if ((spins & 0xFFFFF) == 0xFFFFF) {          // ~ every few ms: has the stream died?
-        hipError_t q = hipStreamQuery(s);
-        if (q != hipSuccess && q != hipErrorNotReady) return set_err(QPGPU_ERR_HIP, std::string("stream error while waiting: ") + hipGetErrorString(q));
-        if (q == hipSuccess && *flag != seq && spins > (1ULL << 26)) break;   // kernel finished but flag never arrived: fall back
+        if ((spins & 0x3F) == 0x3F && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget_us)) napping = true;
+      } else {
+        struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr);
+        if ((++naps & 0x3F) == 0) {                  // every ~few ms: has the stream died?
+          hipError_t q = hipStreamQuery(s);
+          if (q != hipSuccess && q != hipErrorNotReady) return set_err(QPGPU_ERR_HIP, std::string("stream error while waiting: ") + hipGetErrorString(q));
+          if (q == hipSuccess && *flag != seq && naps > 4096) break;   // kernel finished but the flag never arrived: fall back
+        }
       }
     }
   }
   HIP_TRY(hipMemcpyAsync(w->pinned, src, words * 8, hipMemcpyDeviceToHost, s));
+  if (extra) HIP_TRY(hipMemcpyAsync(w->pinned + words, extra, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
@@ -237,21 +277,24 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
 // `fork` (optional) forks work onto the side stream: by default after the leaf hash, beside the latency-bound tree levels
 // (which run at raised wave priority); QPGPU_SPLIT_FORK_LATE=0 forks it before the leaf hash instead (the leaf kernel at
 // N = 2^17 only offers 2 waves/SIMD and leaves issue slots unused, but sharing slows it by more than the overlap gains).
+struct SaltSrc { const u64* host = nullptr; bool have_key = false; SaltKey key{}; u64 stream = 0; };   // explicit columns, or ChaCha8(key, stream)
 template <class F>
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
-                          u64 salt_seed, const u64* salts_host, hipStream_t s, F fork) {
+                          const SaltSrc& salt, hipStream_t s, F fork) {
   const size_t N = c->N;
   { ProfScope ps(w, s, PF_LDE, 8.0 * cols * (c->n + N));
     lde_batch(coeffs, c->n, lde, N, cols, c->log_n, c->rate, c->d_lde_scale, c->pl, s, w->shared_gpu); }
   int width = cols;
   if (c->salt && oracle > 0) {
-    if (salts_host) (void)hipMemcpyAsync(lde + (size_t)cols * N, salts_host + (size_t)(oracle - 1) * 4 * N, 4 * N * 8, hipMemcpyHostToDevice, s);
-    else salt_fill(lde + (size_t)cols * N, N, salt_seed, oracle - 1, s);
+    if (salt.host) {
+      (void)hipMemcpyAsync(lde + (size_t)cols * N, salt.host + (size_t)(oracle - 1) * 4 * N, 4 * N * 8, hipMemcpyHostToDevice, s);
+      check_canonical(lde + (size_t)cols * N, 4 * N, w->pow_result + 1, s);      // explicit salts are caller data: must be canonical
+    } else salt_fill(lde + (size_t)cols * N, N, salt.key, salt.stream, oracle - 1, s);
     width += 4;
   }
   // side-stream work is forked after the leaf hash, beside the latency-bound tree levels (3.827 vs 3.852 ms on config B; the level
   // kernels run at raised wave priority); QPGPU_SPLIT_FORK_LATE=0 forks it before the leaf hash instead
-  static const int fork_late = getenv_int("QPGPU_SPLIT_FORK_LATE", 1);
+  const int fork_late = opts().split_fork_late;
   if (!fork_late) fork();
   int done = 0;
   { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
@@ -261,8 +304,8 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
     merkle_levels(dig, N, c->cap_h, s, done, w->batch_mode); }
 }
 static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int cols, u64* lde, u64* dig, int oracle,
-                          u64 salt_seed, const u64* salts_host, hipStream_t s) {
-  commit_coeffs(c, w, coeffs, cols, lde, dig, oracle, salt_seed, salts_host, s, [] {});
+                          const SaltSrc& salt, hipStream_t s) {
+  commit_coeffs(c, w, coeffs, cols, lde, dig, oracle, salt, s, [] {});
 }
 static const u64* cap_ptr(qpgpu_circuit* c, const u64* dig, size_t leaves) {
   return dig + (merkle_total_digests(leaves, c->cap_h) - (size_t(1) << c->cap_h)) * 4;
@@ -321,6 +364,7 @@ int qpgpu_ctx_create(int device, qpgpu_ctx** out) { return abi_guard([&]() -> in
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return set_err(QPGPU_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   HIP_TRY(hipSetDevice(device));
+  options_refresh_from_env();        // the one read of the QPGPU_* knobs (options.h)
   *out = new qpgpu_ctx{device};
   return 0;
 }); }
@@ -338,7 +382,12 @@ void qpgpu_circuit_destroy(qpgpu_circuit* c) {
 int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_circuit** out) { return abi_guard([&]() -> int {
   if (!ctx || !desc || !out) return set_err(QPGPU_ERR_ARG, "null argument");
   const qpgpu_circuit_desc& d = *desc;
+  if (!d.gates || !d.selector_indices || !d.selector_group_ranges || !d.k_is || !d.constants_sigmas) return set_err(QPGPU_ERR_ARG, "null array in the circuit descriptor");
   if (d.degree_bits < 2 || d.degree_bits + d.fri_rate_bits > 28) return set_err(QPGPU_ERR_ARG, "degree_bits out of range");
+  if (d.num_wires < 1 || d.num_wires > 4096 || d.num_routed < 1 || d.num_routed > d.num_wires) return set_err(QPGPU_ERR_ARG, "need 1 <= num_routed <= num_wires <= 4096");
+  if (d.fri_cap_height > d.degree_bits + d.fri_rate_bits || d.fri_cap_height > 20) return set_err(QPGPU_ERR_ARG, "cap height exceeds tree");
+  if (d.fri_pow_bits > 40) return set_err(QPGPU_ERR_ARG, "proof_of_work_bits out of range");
+  if (d.num_public_inputs > 4096) return set_err(QPGPU_ERR_ARG, "too many public inputs");
   if (d.num_challenges < 1 || d.num_challenges > 2) return set_err(QPGPU_ERR_ARG, "num_challenges must be 1 or 2");
   if (d.num_gates > MAX_GATES || d.num_gates == 0) return set_err(QPGPU_ERR_ARG, "bad gate count");
   if (d.fri_num_layers > MAX_FRI_LAYERS) return set_err(QPGPU_ERR_ARG, "too many FRI layers");
@@ -350,34 +399,47 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   if (d.num_challenges * (1 + d.num_partial_products + d.num_gate_constraints) > 2 * 256 || d.num_gate_constraints + 40 > 256) return set_err(QPGPU_ERR_ARG, "too many constraint terms");
   { uint32_t sum = 0; for (uint32_t i = 0; i < d.fri_num_layers; i++) { if (d.fri_arity_bits[i] < 1 || d.fri_arity_bits[i] > 4) return set_err(QPGPU_ERR_ARG, "FRI arity bits must be 1..4"); sum += d.fri_arity_bits[i]; }
     if (sum > d.degree_bits) return set_err(QPGPU_ERR_ARG, "FRI reductions exceed degree"); }
+  for (uint32_t g = 0; g < d.num_selector_groups; g++) {
+    const uint32_t lo = d.selector_group_ranges[2 * g], hi = d.selector_group_ranges[2 * g + 1];
+    if (lo >= hi || hi > d.num_gates) return set_err(QPGPU_ERR_ARG, "selector group range out of order or beyond the gate list");
+  }
   for (uint32_t i = 0; i < d.num_gates; i++) {
     uint32_t t = d.gates[i].tag;
     const qpgpu_gate& gt = d.gates[i];
     const uint64_t W = d.num_wires, Rt = d.num_routed;
+    uint64_t ncons = 0;          // constraints this gate writes: slots [0, ncons) of the alpha-power table must exist
     switch (t) {
-      case QPGPU_GATE_NOOP: case QPGPU_GATE_CONSTANT: case QPGPU_GATE_PUBLIC_INPUT: case QPGPU_GATE_BASESUM2: case QPGPU_GATE_ARITHMETIC: case QPGPU_GATE_POSEIDON: break;
-      case QPGPU_GATE_ARITHMETIC_EXTENSION: if (8 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "ArithmeticExtension ops exceed routed wires"); break;
-      case QPGPU_GATE_MUL_EXTENSION: if (6 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "MulExtension ops exceed routed wires"); break;
-      case QPGPU_GATE_REDUCING: if (gt.param < 1 || 6 + 3 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "Reducing coefficients exceed wires"); break;
-      case QPGPU_GATE_REDUCING_EXTENSION: if (gt.param < 1 || 6 + 4 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "ReducingExtension coefficients exceed wires"); break;
+      case QPGPU_GATE_NOOP: break;
+      case QPGPU_GATE_CONSTANT: ncons = gt.param; break;
+      case QPGPU_GATE_PUBLIC_INPUT: ncons = 4; if (W < 4) return set_err(QPGPU_ERR_ARG, "PublicInput gate needs 4 wires"); break;
+      case QPGPU_GATE_BASESUM2: ncons = gt.param + 1; break;
+      case QPGPU_GATE_ARITHMETIC: ncons = gt.param; break;
+      case QPGPU_GATE_POSEIDON: ncons = 123; break;
+      case QPGPU_GATE_ARITHMETIC_EXTENSION: if (8 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "ArithmeticExtension ops exceed routed wires"); ncons = 2 * gt.param; break;
+      case QPGPU_GATE_MUL_EXTENSION: if (6 * gt.param > Rt) return set_err(QPGPU_ERR_ARG, "MulExtension ops exceed routed wires"); ncons = 2 * gt.param; break;
+      case QPGPU_GATE_REDUCING: if (gt.param < 1 || 6 + 3 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "Reducing coefficients exceed wires"); ncons = 2 * gt.param; break;
+      case QPGPU_GATE_REDUCING_EXTENSION: if (gt.param < 1 || 6 + 4 * gt.param - 2 > W) return set_err(QPGPU_ERR_ARG, "ReducingExtension coefficients exceed wires"); ncons = 2 * gt.param; break;
       case QPGPU_GATE_RANDOM_ACCESS: {
         if (gt.param < 1 || gt.param > 4) return set_err(QPGPU_ERR_ARG, "RandomAccess bits must be 1..4");
         uint64_t vec = 1ull << gt.param, routed = (2 + vec) * gt.param2 + gt.param3;
         if (routed > Rt || routed + gt.param * gt.param2 > W || gt.param3 + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "RandomAccess copies exceed wires/constants");
+        ncons = (gt.param + 2) * gt.param2 + gt.param3;
         break;
       }
-      case QPGPU_GATE_POSEIDON_MDS: if (W < 48) return set_err(QPGPU_ERR_ARG, "PoseidonMds gate needs 48 wires"); break;
-      case QPGPU_GATE_EXPONENTIATION: if (gt.param < 1 || 2 + 2 * gt.param > W) return set_err(QPGPU_ERR_ARG, "Exponentiation bits exceed wires"); break;
+      case QPGPU_GATE_POSEIDON_MDS: if (W < 48) return set_err(QPGPU_ERR_ARG, "PoseidonMds gate needs 48 wires"); ncons = 24; break;
+      case QPGPU_GATE_EXPONENTIATION: if (gt.param < 1 || 2 + 2 * gt.param > W) return set_err(QPGPU_ERR_ARG, "Exponentiation bits exceed wires"); ncons = gt.param + 1; break;
       case QPGPU_GATE_COSET_INTERPOLATION: {
         if (gt.param < 1 || gt.param > 4 || gt.param2 < 2 || !gt.table || gt.table_len != (1u << gt.param)) return set_err(QPGPU_ERR_ARG, "CosetInterpolation needs subgroup_bits 1..4, degree >= 2 and 2^bits weights");
         uint64_t np = 1ull << gt.param, ni = (np - 2) / (gt.param2 - 1);
         if (1 + 2 * np + 4 + 4 * ni + 2 > W) return set_err(QPGPU_ERR_ARG, "CosetInterpolation exceeds wires");
         for (uint32_t k = 0; k < gt.table_len; k++) if (gt.table[k] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical barycentric weight");
         for (uint32_t j = 0; j < i; j++) if (d.gates[j].tag == QPGPU_GATE_COSET_INTERPOLATION) return set_err(QPGPU_ERR_ARG, "one CosetInterpolation gate per circuit");
+        ncons = 4 + 4 * ni;
         break;
       }
       default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(t) + " is not supported by this backend (lookup gates)");
     }
+    if (ncons > d.num_gate_constraints) return set_err(QPGPU_ERR_ARG, "num_gate_constraints (" + std::to_string(d.num_gate_constraints) + ") is smaller than gate " + std::to_string(i) + "'s " + std::to_string(ncons) + " constraints");
     if (d.selector_indices[i] >= d.num_selector_groups) return set_err(QPGPU_ERR_ARG, "selector index out of range");
     if (t == QPGPU_GATE_POSEIDON && d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires");
     if (t == QPGPU_GATE_BASESUM2 && d.gates[i].param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires");
@@ -385,7 +447,8 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
     if (t == QPGPU_GATE_CONSTANT && d.gates[i].param + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants");
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  qpgpu_circuit* c = new qpgpu_circuit();
+  struct CircuitGuard { qpgpu_circuit* p; ~CircuitGuard() { if (p) qpgpu_circuit_destroy(p); } } guard{new qpgpu_circuit()};   // freed (device memory too) on every early exit, exceptions included
+  qpgpu_circuit* c = guard.p;
   c->ctx = ctx; c->device = ctx->device; c->d = d;
   c->gates.assign(d.gates, d.gates + d.num_gates); for (auto& g : c->gates) g.table = nullptr;   /* weights live in cd.coset_w */ c->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
   c->groups.assign(d.selector_group_ranges, d.selector_group_ranges + 2 * d.num_selector_groups);
@@ -395,18 +458,18 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   c->log_n = d.degree_bits; c->rate = d.fri_rate_bits; c->log_N = c->log_n + c->rate; c->n = size_t(1) << c->log_n; c->N = size_t(1) << c->log_N;
   c->S = d.num_constants + d.num_routed; c->W = d.num_wires; c->nch = d.num_challenges; c->Zp = c->nch * (1 + d.num_partial_products);
   c->Q = c->nch * d.quotient_degree_factor; c->salt = d.zero_knowledge ? 4 : 0; c->cap_h = d.fri_cap_height; c->nlayers = d.fri_num_layers;
-  if ((size_t(1) << c->cap_h) > c->N) { delete c; return set_err(QPGPU_ERR_ARG, "cap height exceeds tree"); }
+  if ((size_t(1) << c->cap_h) > c->N) return set_err(QPGPU_ERR_ARG, "cap height exceeds tree");
   c->fri_log_n[0] = c->log_n;
   for (int l = 0; l < c->nlayers; l++) {
     c->arity[l] = d.fri_arity_bits[l]; c->fri_log_n[l + 1] = c->fri_log_n[l] - c->arity[l];
-    if (c->fri_log_n[l] + c->rate - c->arity[l] < c->cap_h) { delete c; return set_err(QPGPU_ERR_ARG, "FRI layer tree smaller than its cap"); }
+    if (c->fri_log_n[l] + c->rate - c->arity[l] < c->cap_h) return set_err(QPGPU_ERR_ARG, "FRI layer tree smaller than its cap");
   }
   // ---- layout
   compute_layout(d, c->lay);
   const size_t capn = size_t(1) << c->cap_h;
   // ---- device constants
   hipStream_t s = 0;
-#define CC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(e_); qpgpu_circuit_destroy(c); return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, m); } } while (0)
+#define CC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(e_); return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, m); } } while (0)
   const size_t n = c->n, N = c->N;
   CC_TRY(hipMalloc((void**)&c->d_rt, (N / 2 + 1) * 8));
   build_root_table(c->d_rt, c->log_N, s);
@@ -444,23 +507,23 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   // L_0 on the LDE coset (circuit constant; filled once the root table exists, below)
   CC_TRY(hipMalloc((void**)&c->d_l0, N * 8));
   l0_table(c->cd, c->d_l0, c->pl, s);
-  c->cd.l0_lde = getenv_int("QPGPU_L0_TABLE", 1) ? c->d_l0 : nullptr;      // 0: recompute L_0 per point (A/B switch)
+  c->cd.l0_lde = opts().l0_table ? c->d_l0 : nullptr;      // 0: recompute L_0 per point (A/B switch)
   // preprocessed oracle: constants/sigmas values -> coeffs -> LDE -> Merkle (kept resident)
   CC_TRY(hipMalloc((void**)&c->d_cs_vals, (size_t)c->S * n * 8));
   CC_TRY(hipMalloc((void**)&c->d_cs_coeffs, (size_t)c->S * n * 8));
   CC_TRY(hipMalloc((void**)&c->d_cs_lde, (size_t)c->S * N * 8));
   CC_TRY(hipMalloc((void**)&c->d_cs_dig, merkle_total_digests(N, c->cap_h) * 32));
   CC_TRY(hipMemcpy(c->d_cs_vals, d.constants_sigmas, (size_t)c->S * n * 8, hipMemcpyHostToDevice));
-  Workspace* nows = new Workspace();   // no profiling events for the one-off preprocessing
-  values_to_coeffs(c, nows, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
-  c->cs_cap.resize(capn * 4);
-  commit_coeffs(c, nows, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, 0, nullptr, s);
-  CC_TRY(hipStreamSynchronize(s));
-  nows->pev_used = 0; ws_destroy(nows);
+  { struct WsGuard { Workspace* p; ~WsGuard() { if (p) { p->pev_used = 0; ws_destroy(p); } } } nows{new Workspace()};   // no profiling events for the one-off preprocessing
+    values_to_coeffs(c, nows.p, c->d_cs_vals, c->S, c->d_cs_lde, c->d_cs_coeffs, s);
+    c->cs_cap.resize(capn * 4);
+    commit_coeffs(c, nows.p, c->d_cs_coeffs, c->S, c->d_cs_lde, c->d_cs_dig, 0, SaltSrc(), s);
+    CC_TRY(hipStreamSynchronize(s)); }
   CC_TRY(hipGetLastError());
   { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
   c->split_quotient = quotient_split_supported(c->cd) && c->leaf_gates_only;
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
+  guard.p = nullptr;
   *out = c; return 0;
 }); }
 
@@ -559,29 +622,37 @@ static thread_local double g_stage_ms[16]; static thread_local int g_stage_n = 0
 int qpgpu_last_stage_ms(double* out, int cap) { int k = g_stage_n < cap ? g_stage_n : cap; for (int i = 0; i < k; i++) out[i] = g_stage_ms[i]; return g_stage_n; }
 
 static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64_t* wires, const uint64_t* pis, const qpgpu_prove_opts* opts,
-                     u64 salt_seed, const u64* salts_host, uint8_t* out) {
+                     const SaltSrc& salt, uint8_t* out) {
   const size_t n = c->n, N = c->N; const qpgpu_circuit_desc& d = c->d; const Layout& L = c->lay;
   const int nch = c->nch, npp = d.num_partial_products; const size_t capn = size_t(1) << c->cap_h;
-  const bool timing = getenv_int("QPGPU_TIMING", 0) != 0;
+  const bool timing = qp::opts().timing != 0;
   struct StageEvents { hipEvent_t ev[16]; int n = 0; ~StageEvents() { for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]); } } se;
   hipEvent_t* ev = se.ev; int& nev = se.n;
   auto mark = [&]() { if (timing && nev < 16) { if (hipEventCreate(&ev[nev]) == hipSuccess) { (void)hipEventRecord(ev[nev], s); nev++; } } };
   for (uint32_t i = 0; i < d.num_public_inputs; i++) if (pis[i] >= GL_P) return set_err(QPGPU_ERR_WITNESS, "non-canonical public input");
+  if (c->salt && !salt.host && !salt.have_key) return set_err(QPGPU_ERR_ARG, "zero-knowledge circuit: opts.salts or opts.salt_key (32 random bytes) is required");
   u64* pin = w->pinned;
   mark();
+  // the PoW result slot and the non-canonical-input flag behind it are re-armed by the previous proof's query_gather; an explicit
+  // reset is needed only after workspace creation or an aborted proof
+  if (!w->pow_armed) { HIP_TRY(hipMemsetAsync(w->pow_result, 0xFF, 8, s)); HIP_TRY(hipMemsetAsync(w->pow_result + 1, 0, 8, s)); }
+  w->pow_armed = false;
   // ---- 1/2: witness in, wires commitment
   const u64* wires_vals = (const u64*)wires;
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
+  check_canonical(wires_vals, (size_t)c->W * n, w->pow_result + 1, s);       // a wire >= p would flow through the lazy arithmetic and be copied raw into query rows
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
   const bool split = c->split_quotient && !w->batch_mode;
-  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt_seed, salts_host, s, [&] {
-    if (!split || getenv_int("QPGPU_SPLIT_SERIAL", 0)) return;   // gate-constraint terms: only wires + constants, run beside the wires leaf hash
+  const bool split_serial = qp::opts().split_serial != 0;
+  commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt, s, [&] {
+    if (!split || split_serial) return;   // gate-constraint terms: only wires + constants, run beside the wires leaf hash
     (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
     quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, w->side);
     (void)hipEventRecord(w->ev_gates, w->side);
   });
-  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4, w->pow_result + 1); if (rc_) return rc_; }
+  if (pin[capn * 4] != 0) return set_err(QPGPU_ERR_WITNESS, "non-canonical field element (>= p) in the wire matrix" + std::string(salt.host ? " or the salts" : ""));
   mark();
   memcpy(out, pin, L.cap_bytes);
   Transcript tr(nch); Challenger& ch = tr.ch;
@@ -591,8 +662,8 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { ProfScope ps(w, s, PF_ZPP, 8.0 * n * (2.0 * d.num_routed + c->Zp));
     zpp_compute(c->cd, wires_vals, c->d_cs_vals + (size_t)d.num_constants * n, betas, gammas, w->zpp_scratch, w->zs_vals, c->pl, s); }
   values_to_coeffs(c, w, w->zs_vals, c->Zp, w->zs_lde, w->zs_coeffs, s);
-  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt_seed, salts_host, s, [&] {
-    if (!split || getenv_int("QPGPU_SPLIT_SERIAL", 0)) return;   // permutation terms: beta/gamma + Z oracle, run beside the Z leaf hash
+  commit_coeffs(c, w, w->zs_coeffs, c->Zp, w->zs_lde, w->zs_dig, 2, salt, s, [&] {
+    if (!split || split_serial) return;   // permutation terms: beta/gamma + Z oracle, run beside the Z leaf hash
     (void)hipEventRecord(w->ev_fork, s); (void)hipStreamWaitEvent(w->side, w->ev_fork, 0);
     quotient_perm_terms(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->q_perm_terms, c->pl, w->side);
     (void)hipEventRecord(w->ev_perm, w->side);
@@ -605,14 +676,14 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   const int nterms = nch + nch * (npp + 1) + d.num_gate_constraints;
   alpha_powers(w->alpha_pows, alphas, nch, nterms, s);
   { ProfScope ps(w, s, PF_QUOTIENT, 8.0 * N * (c->S + c->W + c->Zp + 2 * nch));
-    if (split && getenv_int("QPGPU_SPLIT_SERIAL", 0)) {        // diagnostic: the three split kernels back to back on the main stream
+    if (split && split_serial) {        // diagnostic: the three split kernels back to back on the main stream
       quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, s);
       quotient_perm_terms(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->q_perm_terms, c->pl, s);
       quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
     } else if (split) {
       (void)hipStreamWaitEvent(s, w->ev_gates, 0); (void)hipStreamWaitEvent(s, w->ev_perm, 0);
       quotient_combine(c->cd, w->q_perm_terms, w->q_gate_terms, w->alpha_pows, nterms, w->q_vals, s);
-    } else if (!w->shared_gpu && getenv_int("QPGPU_QUOTIENT_HALVES", 0)) {
+    } else if (!w->shared_gpu && qp::opts().quotient_halves) {
       // single proof: the permutation half and the gate half run at once on two streams (each alone offers only 2 waves/SIMD
       // and stalls on its loads); q_lde is free until the quotient commitment and serves as scratch for the two partial sums
       u64* pa = w->q_lde; u64* pb = w->q_lde + (size_t)nch * N;
@@ -625,8 +696,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
-  commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt_seed, salts_host, s);
-  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4); if (rc_) return rc_; }
+  commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt, s);
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4, salt.host ? w->pow_result + 1 : nullptr); if (rc_) return rc_; }
+  if (salt.host && pin[capn * 4] != 0) return set_err(QPGPU_ERR_WITNESS, "non-canonical field element (>= p) in the salts");
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
   Ext zeta = tr.after_quotient_cap(pin, capn * 4);
@@ -695,9 +767,6 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     for (int i = 0; i < ch.n_in; i++) sp.s[i] = ch.in[i];
     const int pos = ch.n_in;
     u64 none = ~0ULL; pow_witness = none;
-    // the result slot is re-armed by the previous proof's query_gather; an explicit reset only after workspace creation or an aborted proof
-    if (!w->pow_armed) { HIP_TRY(hipMemcpyAsync(w->pow_result, &none, 8, hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
-    w->pow_armed = false;
     u64 base = 0, span = 1ULL << 17;
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
@@ -740,6 +809,15 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     for (int i = 0; i + 1 < nev; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); g_stage_ms[i] = ms; }
   }
   return 0;
+}
+
+// proof `index` of a call: explicit salts advance by one proof's columns, a keyed stream by one nonce
+static SaltSrc salt_source(const qpgpu_prove_opts* o, size_t index, size_t N) {
+  SaltSrc s;
+  if (!o) return s;
+  if (o->salts) s.host = o->salts + index * 3 * 4 * N;
+  else if (o->salt_key) { s.have_key = true; s.key = salt_key_from_bytes(o->salt_key); s.stream = o->salt_stream + index; }
+  return s;
 }
 
 extern "C" {
@@ -804,8 +882,8 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
   HIP_TRY(hipSetDevice(c->device));
   Workspace* w = nullptr; int rc = ws_acquire(c, &w); if (rc) return rc;
   hipStream_t s = (opts && opts->stream) ? (hipStream_t)opts->stream : w->stream;
-  rc = prove_one(c, w, s, wires, public_inputs, opts, opts ? opts->salt_seed : 0, opts ? opts->salts : nullptr, out);
-  if (rc != 0) { (void)hipStreamSynchronize(s); w->pev_used = 0; }
+  rc = prove_one(c, w, s, wires, public_inputs, opts, salt_source(opts, 0, c->N), out);
+  if (rc != 0) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(w->side); w->pev_used = 0; }      // nothing of this proof may still run when the workspace is recycled
   ws_release(c, w);
   if (rc == 0 && out_len) *out_len = c->lay.total;
   return rc;
@@ -817,21 +895,20 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
   if (num_public_inputs != c->d.num_public_inputs) return set_err(QPGPU_ERR_ARG, "public input count mismatch");
   if (out_stride < c->lay.total) return set_err(QPGPU_ERR_BUFFER, "out_stride smaller than proof size");
   if (batch == 0) return 0;
-  int workers = getenv_int("QPGPU_STREAMS", 4); if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
+  int workers = qp::opts().streams; if (workers < 1) workers = 1; if ((size_t)workers > batch) workers = (int)batch;
   std::atomic<size_t> next(0); std::atomic<int> first_rc(0); std::mutex emu; std::string emsg;
   auto body_inner = [&]() {
     if (hipSetDevice(c->device) != hipSuccess) { first_rc = QPGPU_ERR_HIP; return; }
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
     w->batch_mode = workers > 1;
-    w->shared_gpu = getenv_int("QPGPU_SHARED_MODE", 0) != 0;   // the batch-mode kernel choices stopped paying once the field arithmetic got cheaper (profiles/r01_notes_ab_experiments.md)
+    w->shared_gpu = qp::opts().shared_mode != 0;   // the batch-mode kernel choices stopped paying once the field arithmetic got cheaper (profiles/r01_notes_ab_experiments.md)
     for (;;) {
       size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
       qpgpu_prove_opts o; if (opts) o = *opts; else memset(&o, 0, sizeof o);
       o.stream = nullptr;
-      const u64* salts = (opts && opts->salts) ? opts->salts + i * 3 * 4 * c->N : nullptr;
-      rc = prove_one(c, w, w->stream, wires[i], public_inputs[i], &o, o.salt_seed + i, salts, out + i * out_stride);
-      if (rc) { (void)hipStreamSynchronize(w->stream); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
+      rc = prove_one(c, w, w->stream, wires[i], public_inputs[i], &o, salt_source(opts, i, c->N), out + i * out_stride);
+      if (rc) { (void)hipStreamSynchronize(w->stream); (void)hipStreamSynchronize(w->side); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
       if (out_lens) out_lens[i] = c->lay.total;
     }
     w->shared_gpu = false; w->batch_mode = false;

@@ -6,6 +6,7 @@
 //   k_quotient_combine — after alpha is known: sum_i alpha^i term_i / Z_H(x) over the stored columns (a 145-column dot product).
 // Same arithmetic as the fused kernel in plonk.hip, which remains the default (see quotient_split_supported for the A/B numbers).
 #include "kernels.h"
+#include "options.h"
 #include "poseidon.h"
 #include "poseidon_dev.h"
 #include "../../include/qpgpu.h"
@@ -195,9 +196,9 @@ bool quotient_split_supported(const CircuitDev& cd) {
   // 2 waves/SIMD), the permutation terms beside the Z leaf hash, and only the alpha combination stays on the critical path.
   // MI355X, config B: single proof 3.89 vs 4.00 ms. Stream-pipelined batches keep the fused kernel (336 vs 341 proofs/s: the extra
   // ~300 MB of traffic buys nothing when other proofs already fill the chip) — qpgpu_prove_batch switches it off per call.
-  const char* v = getenv("QPGPU_SPLIT_QUOTIENT");
-  if (v && v[0] == '0') return false;
-  if (cd.log_n + cd.rate_bits > 20 && !(v && v[0] == '1')) return false;     // 145 extra columns of N per workspace
+  const int v = opts().split_quotient;
+  if (v == 0) return false;
+  if (cd.log_n + cd.rate_bits > 20 && v != 1) return false;     // 145 extra columns of N per workspace
   int seen[16] = {0}; bool poseidon = false;
   for (int i = 0; i < cd.num_gates; i++) {
     u32 t = cd.gates[i].tag; if (t >= 16 || seen[t]++) return false;

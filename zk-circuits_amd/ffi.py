@@ -46,8 +46,22 @@ class SynthParams(ctypes.Structure):
 
 
 class ProveOpts(ctypes.Structure):
-    _fields_ = [("salts", u64p), ("salt_seed", ctypes.c_uint64), ("pow_witness", ctypes.c_uint64),
+    _fields_ = [("salts", u64p), ("salt_key", ctypes.POINTER(ctypes.c_uint8)), ("salt_stream", ctypes.c_uint64), ("pow_witness", ctypes.c_uint64),
                 ("have_pow_witness", ctypes.c_uint32), ("wires_on_device", ctypes.c_uint32), ("stream", ctypes.c_void_p)]
+
+
+# include/qpsynth.h QPSYNTH_TEST_SALT_KEY_BYTES: the fixed PUBLIC ChaCha8 key the tests and bench.py use with salt_stream = seed, so
+# that the oracle side can reproduce the salts (qpsynth_salts). Production callers pass 32 bytes from the OS RNG instead.
+TEST_SALT_KEY = bytes([0x51, 0x50, 0x2d, 0x74, 0x65, 0x73, 0x74, 0x2d, 0x73, 0x61, 0x6c, 0x74, 0x2d, 0x6b, 0x65, 0x79]) + bytes(range(16))
+
+
+def set_salt_key(opts, key):
+    """Points opts.salt_key at a 32-byte key; returns the buffer, which must stay alive for the duration of the call."""
+    if len(key) != 32:
+        raise ValueError("salt_key must be 32 bytes")
+    buf = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(key))
+    opts.salt_key = ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8))
+    return buf
 
 
 _lib = None
@@ -123,6 +137,8 @@ def synth_lib():
         L.qpsynth_circuit_desc.argtypes = [ctypes.c_void_p]
         L.qpsynth_witness.argtypes = [ctypes.c_void_p, ctypes.c_uint64, u64p, u64p]
         L.qpsynth_salts.argtypes = [ctypes.c_void_p, ctypes.c_uint64, u64p]
+        L.qpsynth_salts_keyed.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, u64p]
+        L.qpsynth_salt_block.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, u64p]
         _synth = L
     return _synth
 
@@ -177,6 +193,11 @@ class SynthCircuit:
         synth().qpsynth_salts(self.handle, salt_seed, ptr(out))
         return out
 
+    def salts_keyed(self, key, stream):
+        out = np.zeros((3, 4, self.N), dtype=np.uint64)
+        synth().qpsynth_salts_keyed(self.handle, bytes(key), stream, ptr(out))
+        return out
+
     def constants_sigmas(self):
         d = self.desc
         S = d.num_constants + d.num_routed
@@ -206,11 +227,14 @@ class GpuCircuit:
         gpu_check(qpgpu().qpgpu_circuit_constants_sigmas_cap(self.h, ptr(out)))
         return out
 
-    def prove(self, wires, pis, salts=None, salt_seed=0, pow_witness=None, wires_dev_ptr=None, stream=None):
+    def prove(self, wires, pis, salts=None, salt_seed=0, pow_witness=None, wires_dev_ptr=None, stream=None, salt_key=TEST_SALT_KEY):
+        """salts: explicit columns; otherwise ChaCha8(salt_key, stream = salt_seed). The default key is the public test key (so that
+        qpsynth_salts(salt_seed) reproduces the salts); salt_key=None sends no key at all (a zk circuit then refuses to prove)."""
         L = qpgpu()
         o = ProveOpts()
         o.salts = ptr(salts) if salts is not None else None
-        o.salt_seed = salt_seed
+        o.salt_stream = salt_seed
+        keep = set_salt_key(o, salt_key) if (salt_key is not None and salts is None) else None   # noqa: F841 (kept alive until the call returns)
         o.have_pow_witness = 0 if pow_witness is None else 1
         o.pow_witness = 0 if pow_witness is None else pow_witness
         o.wires_on_device = 0 if wires_dev_ptr is None else 1
@@ -225,11 +249,12 @@ class GpuCircuit:
         gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
         return ctypes.string_at(buf, n.value)          # one copy (buf.raw[:n] makes two)
 
-    def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False):
+    def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False, salt_key=TEST_SALT_KEY):
         L = qpgpu()
         b = len(pis_list)
         o = ProveOpts()
-        o.salt_seed = salt_seed
+        o.salt_stream = salt_seed                                   # proof i uses stream salt_seed + i
+        keep = set_salt_key(o, salt_key) if salt_key is not None else None   # noqa: F841
         o.wires_on_device = 1 if wires_on_device else 0
         if wires_on_device:
             wp = (ctypes.c_void_p * b)(*wires_list)

@@ -11,7 +11,10 @@
 #include "../../include/qpgpu.h"
 #include "../../include/qpsynth.h"
 #include <cstdint>
+#include <array>
+#include <cstring>
 #include <memory>
+#include <random>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -34,7 +37,15 @@ struct ProofWithPublicInputs {
 struct CircuitInputs {                        // stand-in for wormhole_circuit::inputs::CircuitInputs: a full witness
   std::vector<uint64_t> wires;                // [num_wires][n], column-major
   std::vector<uint64_t> public_inputs;        // [16]
-  uint64_t salt_seed = 0;
+  // zk salts = ChaCha8(salt_key, salt_stream) on the device (include/qpgpu.h). test_inputs() uses the public test key with
+  // stream = seed so the bytes are reproducible; a real witness gets 32 bytes from the OS RNG (what F::rand_vec does upstream).
+  std::array<uint8_t, 32> salt_key{}; uint64_t salt_stream = 0;
+  static std::array<uint8_t, 32> random_salt_key() {
+    std::array<uint8_t, 32> k{}; std::random_device rd;
+    for (size_t i = 0; i < k.size(); i += 4) { uint32_t v = rd(); memcpy(&k[i], &v, 4); }
+    return k;
+  }
+  CircuitInputs() : salt_key(random_salt_key()) {}
 };
 
 class CircuitData {                           // ProverCircuitData: resident on the GPU, shareable between provers
@@ -55,8 +66,9 @@ class CircuitData {                           // ProverCircuitData: resident on 
   CircuitInputs test_inputs(uint64_t index = 0) const {     // CircuitInputs::test_inputs() analogue (seed 0x51570000 + index)
     CircuitInputs in; size_t n = size_t(1) << desc_->degree_bits;
     in.wires.resize((size_t)desc_->num_wires * n); in.public_inputs.resize(desc_->num_public_inputs);
-    in.salt_seed = 0x51570000ULL + index;
-    qpsynth_witness(synth_, in.salt_seed, in.wires.data(), in.public_inputs.data());
+    static const uint8_t test_key[32] = {QPSYNTH_TEST_SALT_KEY_BYTES};
+    memcpy(in.salt_key.data(), test_key, 32); in.salt_stream = 0x51570000ULL + index;
+    qpsynth_witness(synth_, in.salt_stream, in.wires.data(), in.public_inputs.data());
     return in;
   }
  private:
@@ -82,7 +94,7 @@ class WormholeProver {
   ProofWithPublicInputs prove() {
     if (!witness_) throw std::runtime_error("Failed to prove: prover has not commited to any inputs");
     ProofWithPublicInputs out; out.bytes.resize(circuit_data->proof_size());
-    qpgpu_prove_opts o{}; o.salt_seed = witness_->salt_seed;
+    qpgpu_prove_opts o{}; o.salt_key = witness_->salt_key.data(); o.salt_stream = witness_->salt_stream;
     size_t len = 0;
     int rc = qpgpu_prove(circuit_data->handle(), witness_->wires.data(), witness_->public_inputs.data(), witness_->public_inputs.size(), &o,
                          out.bytes.data(), out.bytes.size(), &len);

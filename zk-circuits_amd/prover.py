@@ -6,6 +6,7 @@ uploads it to the GPU once; `commit(inputs)` fills the witness and may be called
 `ProofWithPublicInputs` whose bytes are plonky2's `to_bytes()` layout.
 """
 import ctypes
+import os
 import numpy as np
 from . import ffi
 
@@ -36,10 +37,10 @@ class CircuitInputs:
     """Stand-in for wormhole_circuit::inputs::CircuitInputs (wormhole/circuit/src/inputs.rs:23-55): a witness seed for
     the synthetic generator, or an explicit full witness (wires [W][n], public_inputs [16])."""
 
-    def __init__(self, seed=None, wires=None, public_inputs=None):
+    def __init__(self, seed=None, wires=None, public_inputs=None, salt_key=None):
         if (seed is None) == (wires is None):
             raise ValueError("give either a seed or an explicit witness")
-        self.seed, self.wires, self.public_inputs = seed, wires, public_inputs
+        self.seed, self.wires, self.public_inputs, self.salt_key = seed, wires, public_inputs, salt_key
 
     @staticmethod
     def test_inputs(index=0):
@@ -96,6 +97,23 @@ class WormholeCircuitData:
         ffi.synth_lib().qpsynth_witness(self._synth, seed, wires.ctypes.data_as(ffi.u64p), pis.ctypes.data_as(ffi.u64p))
         return wires, pis
 
+    DUMMY_SEED = 0x5157D0D0
+
+    def dummy_proof(self):
+        """The padding proof of this leaf circuit: a genuine proof of fixed, public dummy inputs, made once per circuit — what the
+        reference exports with its #[ignore] tests (wormhole/tests/src/prover/prover_tests.rs:56-82) and embeds as DUMMY_PROOF_BYTES
+        (wormhole/aggregator/src/util.rs:6-9). The reference's own blobs belong to its real circuit (other digest) and cannot pad a
+        synthetic one."""
+        if getattr(self, "_dummy", None) is None:
+            wires, pis = self.witness(self.DUMMY_SEED)
+            o = ffi.ProveOpts(); o.salt_stream = self.DUMMY_SEED
+            keep = ffi.set_salt_key(o, ffi.TEST_SALT_KEY)      # noqa: F841  (public inputs of the dummy are public anyway)
+            buf = ctypes.create_string_buffer(self.proof_size); n = ctypes.c_size_t()
+            ffi.check(ffi.lib().qpgpu_prove(self._circuit, wires.ctypes.data, pis.ctypes.data_as(ffi.u64p), len(pis), ctypes.byref(o),
+                                            buf, self.proof_size, ctypes.byref(n)))
+            self._dummy = ProofWithPublicInputs(ctypes.string_at(buf, n.value), self.num_public_inputs)
+        return self._dummy
+
     def constants_sigmas_cap(self):
         out = np.zeros((1 << self.desc.fri_cap_height, 4), dtype=np.uint64)
         ffi.check(ffi.lib().qpgpu_circuit_constants_sigmas_cap(self._circuit, out.ctypes.data_as(ffi.u64p)))
@@ -126,10 +144,12 @@ class WormholeProver:
             pis = np.ascontiguousarray(circuit_inputs.public_inputs, dtype=np.uint64)
             if wires.shape != (cd.num_wires, cd.n) or pis.shape != (cd.num_public_inputs,):
                 raise ValueError("witness shape mismatch")
-            self._salt_seed = 0
+            # a real witness: salts come from the OS RNG, as qp-plonky2's F::rand_vec does (32 key bytes, expanded on the device)
+            self._salt_key, self._salt_stream = (circuit_inputs.salt_key or os.urandom(32)), 0
         else:
             wires, pis = cd.witness(circuit_inputs.seed)
-            self._salt_seed = circuit_inputs.seed
+            # seeded synthetic inputs (tests, benches): the public test key, so the bytes are reproducible by the oracle
+            self._salt_key, self._salt_stream = ffi.TEST_SALT_KEY, circuit_inputs.seed
         self._witness = (wires, pis)
         return self
 
@@ -140,7 +160,8 @@ class WormholeProver:
         wires, pis = self._witness
         self._witness = None                     # prove(self) consumes the prover (lib.rs:233)
         o = ffi.ProveOpts()
-        o.salt_seed = self._salt_seed
+        o.salt_stream = self._salt_stream
+        keep = ffi.set_salt_key(o, self._salt_key)      # noqa: F841
         if pow_witness is not None:
             o.have_pow_witness, o.pow_witness = 1, pow_witness
         buf = ctypes.create_string_buffer(cd.proof_size)

@@ -399,9 +399,14 @@ int qpsynth_witness(const qpsynth_circuit* c, uint64_t seed, uint64_t* wires, ui
   return 0;
 }
 
-void qpsynth_salts(const qpsynth_circuit* c, uint64_t salt_seed, uint64_t* out) {
-  size_t N = c->n << 3;
-  for (size_t i = 0; i < 12 * N; i++) out[i] = salt_value(salt_seed, i);
+void qpsynth_salts_keyed(const qpsynth_circuit* c, const uint8_t* key32, uint64_t stream, uint64_t* out) {
+  const size_t N = c->n << 3; const SaltKey key = salt_key_from_bytes(key32);
+  for (size_t b = 0; b < 12 * N / 8; b++) salt_block(key, stream, b, out + 8 * b);
 }
+void qpsynth_salts(const qpsynth_circuit* c, uint64_t salt_seed, uint64_t* out) {
+  static const uint8_t test_key[32] = {QPSYNTH_TEST_SALT_KEY_BYTES};
+  qpsynth_salts_keyed(c, test_key, salt_seed, out);
+}
+void qpsynth_salt_block(const uint8_t* key32, uint64_t nonce, uint64_t block, uint64_t* out8) { salt_block(salt_key_from_bytes(key32), nonce, block, out8); }
 
 } // extern "C"
