@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_pmc(counter, outdir, cmd):
+    import shutil
+    shutil.rmtree(os.path.join(ROOT, outdir), ignore_errors=True)      # one workload per directory: rows of an earlier preset must not be averaged in
     env = dict(os.environ, TMPDIR="/tmp")
     full = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "--"] + cmd
     subprocess.run(full, check=True, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -45,8 +47,9 @@ def main():
                  "--no-tree", "--no-pipelined"] + (["--batch", str(args.batch)] if args.batch > 1 else [])
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        c = per_kernel(run_pmc(counter, "gpurun_out/pmc_calib_" + counter, calib_cmd), counter)
-        b = per_kernel(run_pmc(counter, "gpurun_out/pmc_bench_" + counter, bench_cmd), counter)
+        tag = "%s%s_%s" % (args.preset, args.batch if args.batch > 1 else "", counter)
+        c = per_kernel(run_pmc(counter, "gpurun_out/pmc_calib_" + tag, calib_cmd), counter)
+        b = per_kernel(run_pmc(counter, "gpurun_out/pmc_bench_" + tag, bench_cmd), counter)
         res[counter] = (c, b)
     known_fetch = calib_w * calib_n * 8 / 1024.0
     known_write = calib_n * 8 / 1024.0

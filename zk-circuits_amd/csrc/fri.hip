@@ -164,7 +164,7 @@ __device__ __forceinline__ void put_u64(uint8_t* p, u64 v) {
 }
 __global__ void __launch_bounds__(256) k_query_gather(GatherArgs a, uint8_t* out) {
   const int q = blockIdx.x;
-  if (q == 0 && threadIdx.x == 0 && a.pow_reset) { a.pow_reset[0] = ~0ULL; a.pow_reset[1] = 0; }   // PoW result slot + non-canonical-input flag
+  if (q == 0 && threadIdx.x == 0 && a.pow_reset) *a.pow_reset = ~0ULL;
   size_t x = a.idx[q];
   uint8_t* p = out + (size_t)q * a.bytes_per_query;
   const size_t N = size_t(1) << a.log_N;

@@ -42,8 +42,8 @@ void ntt16_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int
 // Device -> host hand-off without a copy engine round trip: a kernel copies `words` u64 from device memory into mapped pinned
 // host memory, fences at system scope and then stores `seq` into *flag (also pinned); the host spins on the flag.
 // Measured 7.5 us per hand-off versus 15.2 us for hipMemcpyAsync + hipStreamSynchronize (tools/ubench notes in DESIGN.md).
-// `extra` (optional): one more device word copied to dst_mapped[words].
-void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s, const u64* extra = nullptr);
+// `extra` (optional): one more device word copied to dst_mapped[words] (and zeroed afterwards if clear_extra).
+void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s, u64* extra = nullptr, bool clear_extra = false);
 bool lde_strided_supported(int log_n);
 // natural-order in -> bit-reversed out (coset blocks as in lde_batch); inverse = conjugate roots, unscaled
 void lde_strided_run(const u64* in, size_t in_stride, u64* out, size_t out_stride, int count, int log_n, int log_cosets, const u64* pre,
@@ -158,7 +158,7 @@ struct GatherFri { const u64* a; const u64* b; const u64* digests; int arity_bit
 struct GatherArgs {
   GatherTree trees[4]; int log_N, cap_height, num_layers; GatherFri layers[MAX_FRI_LAYERS];
   u32 idx[MAX_QUERIES]; int nq; size_t bytes_per_query;
-  u64* pow_reset;              // if set: re-arm the workspace's PoW result slot (atomicMin target) and clear the input flag after it for the next proof
+  u64* pow_reset;              // if set: re-arm the workspace's PoW result slot (atomicMin target) for the next proof
 };
 void query_gather(const GatherArgs& a, uint8_t* out, hipStream_t s);
 

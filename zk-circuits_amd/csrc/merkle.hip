@@ -31,10 +31,10 @@ void check_canonical(const u64* data, size_t count, u64* flag, hipStream_t s) {
   hipLaunchKernelGGL(k_check_canonical, dim3((unsigned)blocks), dim3(256), 0, s, data, count, flag);
 }
 
-__global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq, const u64* extra) {
+__global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_t words, u64* flag, u64* counter, u64 seq, u64* extra, int clear_extra) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound stage: win VALU arbitration against co-resident bulk hashing waves
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-  if (extra && blockIdx.x == 0 && threadIdx.x == 0) dst[words] = *extra;
+  if (extra && blockIdx.x == 0 && threadIdx.x == 0) { dst[words] = *extra; if (clear_extra) *extra = 0; }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -47,9 +47,9 @@ __global__ void __launch_bounds__(256) k_publish(const u64* src, u64* dst, size_
     if (last) { __threadfence_system(); *(volatile u64*)flag = seq; }
   }
 }
-void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s, const u64* extra) {
+void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_mapped, u64* counter_dev, u64 seq, hipStream_t s, u64* extra, bool clear_extra) {
   unsigned blocks = (unsigned)((words + 2047) / 2048); if (blocks < 1) blocks = 1; if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq, extra);
+  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq, extra, clear_extra ? 1 : 0);
 }
 
 __global__ void k_permute_batch(u64* states, size_t count) {

@@ -107,6 +107,7 @@ struct Workspace {
   hipEvent_t pev[PROF_EVENTS]; int pev_made = 0, pev_used = 0; int pev_id[PROF_EVENTS / 2]; double pev_bytes[PROF_EVENTS / 2];
   DevArena arena; hipStream_t stream = nullptr; u64* pinned = nullptr; size_t pinned_elems = 0;
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_gates = nullptr, ev_perm = nullptr;   // off-critical-path quotient parts
+  hipEvent_t ev_in = nullptr, ev_canon = nullptr;                                                      // off-critical-path input check
   u64 *q_gate_terms = nullptr, *q_perm_terms = nullptr;
   u64* pinned_dev = nullptr;   // device-side alias of the mapped pinned buffer; last 8 words: [flag, ...]
   u64* pub_counter = nullptr;  // device counter of multi-block publishes: the last block to arrive resets it (k_publish)
@@ -206,7 +207,8 @@ static int ws_acquire(qpgpu_circuit* c, Workspace** out) {
   {
     // the side stream carries work that runs beside the main stream (the quotient's second half; the opt-in split quotient)
     if (hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_lo) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&w->ev_gates, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_perm, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&w->ev_gates, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_perm, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_canon, hipEventDisableTiming) != hipSuccess) {
       ws_destroy(w); return set_err(QPGPU_ERR_HIP, "side stream / event creation failed");
     }
   }
@@ -228,7 +230,7 @@ static void ws_destroy(Workspace* w) {
   if (w->pinned) (void)hipHostFree(w->pinned);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   if (w->side) (void)hipStreamDestroy(w->side);
-  for (hipEvent_t e : {w->ev_fork, w->ev_gates, w->ev_perm}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {w->ev_fork, w->ev_gates, w->ev_perm, w->ev_in, w->ev_canon}) if (e) (void)hipEventDestroy(e);
   if (w->arena.base) (void)hipFree(w->arena.base);
   delete w;
 }
@@ -239,13 +241,13 @@ static void ws_destroy(Workspace* w) {
 // The wait is adaptive: busy-poll the flag for the spin budget (Options::handoff_spin_us; a hand-off usually lands within it), then nap
 // 20 us between polls so that a stage that runs for a millisecond (the wires leaf hash) does not pin a host core, which matters
 // with 4 worker streams x 8 ranks on one host. Every hand-off also surfaces launch errors of the stage it ends (hipGetLastError).
-static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t words, const u64* extra = nullptr) {
+static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t words, u64* extra = nullptr, bool clear_extra = false) {
   if (words + (extra ? 1 : 0) > w->pinned_elems) return set_err(QPGPU_ERR_BUFFER, "internal: hand-off larger than the pinned buffer");
   { hipError_t le = hipGetLastError(); if (le != hipSuccess) return set_err(QPGPU_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le)); }
   if (w->pinned_dev && !opts().no_publish) {
     const u64 seq = ++w->pub_seq;
     volatile u64* flag = w->pinned + w->pinned_elems;
-    publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s, extra);
+    publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s, extra, clear_extra);
     const int budget_us = opts().handoff_spin_us >= 0 ? opts().handoff_spin_us : (w->batch_mode ? 50 : 2000);
     const auto t0 = std::chrono::steady_clock::now();
     bool napping = false; uint64_t naps = 0;
@@ -268,6 +270,7 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
   }
   HIP_TRY(hipMemcpyAsync(w->pinned, src, words * 8, hipMemcpyDeviceToHost, s));
   if (extra) HIP_TRY(hipMemcpyAsync(w->pinned + words, extra, 8, hipMemcpyDeviceToHost, s));
+  if (extra && clear_extra) HIP_TRY(hipMemsetAsync(extra, 0, 8, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
@@ -640,7 +643,11 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   // ---- 1/2: witness in, wires commitment
   const u64* wires_vals = (const u64*)wires;
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
-  check_canonical(wires_vals, (size_t)c->W * n, w->pow_result + 1, s);       // a wire >= p would flow through the lazy arithmetic and be copied raw into query rows
+  // A wire >= p would flow through the lazy arithmetic and be copied raw into query rows: the whole matrix is checked on the device, on
+  // the side stream (the wires are read-only), and the flag is collected with the proof's last hand-off — before any byte is released.
+  (void)hipEventRecord(w->ev_in, s); (void)hipStreamWaitEvent(w->side, w->ev_in, 0);
+  check_canonical(wires_vals, (size_t)c->W * n, w->pow_result + 1, w->side);
+  (void)hipEventRecord(w->ev_canon, w->side);
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
   values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
   const bool split = c->split_quotient && !w->batch_mode;
@@ -651,8 +658,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     quotient_gate_terms(c->cd, c->d_cs_lde, w->wires_lde, pi_hash, w->q_gate_terms, w->side);
     (void)hipEventRecord(w->ev_gates, w->side);
   });
-  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4, w->pow_result + 1); if (rc_) return rc_; }
-  if (pin[capn * 4] != 0) return set_err(QPGPU_ERR_WITNESS, "non-canonical field element (>= p) in the wire matrix" + std::string(salt.host ? " or the salts" : ""));
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->wires_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out, pin, L.cap_bytes);
   Transcript tr(nch); Challenger& ch = tr.ch;
@@ -697,8 +703,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
   commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt, s);
-  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4, salt.host ? w->pow_result + 1 : nullptr); if (rc_) return rc_; }
-  if (salt.host && pin[capn * 4] != 0) return set_err(QPGPU_ERR_WITNESS, "non-canonical field element (>= p) in the salts");
+  { int rc_ = fetch_to_host(w, s, cap_ptr(c, w->q_dig, N), capn * 4); if (rc_) return rc_; }
   mark();
   memcpy(out + 2 * L.cap_bytes, pin, L.cap_bytes);
   Ext zeta = tr.after_quotient_cap(pin, capn * 4);
@@ -796,9 +801,12 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   ga.nq = d.fri_num_queries; ga.bytes_per_query = L.bytes_per_query; ga.pow_reset = w->pow_result;
   for (int q = 0; q < ga.nq; q++) ga.idx[q] = tr.query_index(N);
   { ProfScope ps(w, s, PF_GATHER, 2.0 * L.bytes_per_query * ga.nq); query_gather(ga, w->query_bytes, s); }
-  { int rc_ = fetch_to_host(w, s, (const u64*)w->query_bytes, (L.bytes_per_query * ga.nq + 7) / 8); if (rc_) return rc_; }
+  const size_t qwords = (L.bytes_per_query * ga.nq + 7) / 8;
+  (void)hipStreamWaitEvent(s, w->ev_canon, 0);                   // the input check (side stream) must have finished before its flag is read
+  { int rc_ = fetch_to_host(w, s, (const u64*)w->query_bytes, qwords, w->pow_result + 1, true); if (rc_) return rc_; }
   HIP_TRY(hipGetLastError());
-  w->pow_armed = true;            // the gather kernel has run (its bytes arrived), so the slot holds ~0 again
+  w->pow_armed = true;            // the gather kernel has run and the flag was collected and cleared: both slots are armed for the next proof
+  if (pin[qwords] != 0) return set_err(QPGPU_ERR_WITNESS, "non-canonical field element (>= p) in the wire matrix" + std::string(salt.host ? " or the salts" : ""));
   memcpy(out + L.queries_off, pin, L.bytes_per_query * ga.nq);
   { u64 npi = d.num_public_inputs; memcpy(out + L.pis_off, &npi, 8); memcpy(out + L.pis_off + 8, pis, 8 * npi); }
   mark();

@@ -55,12 +55,22 @@ class ProveOpts(ctypes.Structure):
 TEST_SALT_KEY = bytes([0x51, 0x50, 0x2d, 0x74, 0x65, 0x73, 0x74, 0x2d, 0x73, 0x61, 0x6c, 0x74, 0x2d, 0x6b, 0x65, 0x79]) + bytes(range(16))
 
 
+_KEY_BUFS = {}
+
+
 def set_salt_key(opts, key):
-    """Points opts.salt_key at a 32-byte key; returns the buffer, which must stay alive for the duration of the call."""
-    if len(key) != 32:
-        raise ValueError("salt_key must be 32 bytes")
-    buf = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(key))
-    opts.salt_key = ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8))
+    """Points opts.salt_key at a 32-byte key. The ctypes buffer is cached per key value (it must outlive the call anyway, and building
+    one per proof costs microseconds inside timed loops); returns it."""
+    key = bytes(key)
+    buf = _KEY_BUFS.get(key)
+    if buf is None:
+        if len(key) != 32:
+            raise ValueError("salt_key must be 32 bytes")
+        if len(_KEY_BUFS) > 64:
+            _KEY_BUFS.clear()
+        raw = (ctypes.c_uint8 * 32).from_buffer_copy(key)
+        buf = _KEY_BUFS[key] = (raw, ctypes.cast(raw, ctypes.POINTER(ctypes.c_uint8)))
+    opts.salt_key = buf[1]
     return buf
 
 
