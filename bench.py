@@ -297,6 +297,17 @@ def main():
                     matrix.append({"branching": b_, "depth": d_, "leaves": cfg_.num_leaf_proofs, "nodes": sum(b_ ** k for k in range(d_)),
                                    "aggregate_ms": round(tb * 1e3, 3)})
                 tree["bench_matrix"] = matrix
+            # the aggregator's intake check: all 64 leaf proofs through the product's batch verifier (device Merkle openings + host algebra)
+            try:
+                ver = H.GpuVerifier(sc.desc, gc.cap(), device=local_rank)
+                ver.verify_batch(leaf_proofs[:8])                                       # warm
+                torch.cuda.synchronize(); tv = time.perf_counter()
+                okv, _ = ver.verify_batch(leaf_proofs)
+                tv = time.perf_counter() - tv
+                tree["leaf_batch_verify"] = {"proofs": len(leaf_proofs), "accepted": int(sum(okv)), "seconds": round(tv, 4), "proofs_per_s": round(len(leaf_proofs) / tv, 1)}
+                ver.close()
+            except Exception as e:
+                tree["leaf_batch_verify"] = {"error": repr(e)[:160]}
             to_check += [("tree_leaf_first", leaf_proofs[0], 0, seeds[0]), ("tree_leaf_last", leaf_proofs[-1], (leaves_per_rank - 1) % nwit, seeds[0] + leaves_per_rank - 1)]
             tree_leaves, tree_root, tree_desc_owner = leaf_proofs, root.proof, scR
             gcR.close()

@@ -30,7 +30,8 @@ typedef enum qpgpu_status {
   QPGPU_ERR_BUFFER = -5,     /* output buffer too small */
   QPGPU_ERR_ZETA = -6,       /* zeta^n == 1 (upstream's "opening point is in the subgroup" exit) */
   QPGPU_ERR_POW = -7,        /* supplied pow_witness invalid, or grinding found nothing */
-  QPGPU_ERR_WITNESS = -8     /* non-canonical field element (>= p) in the wire matrix, the public inputs or explicit salts */
+  QPGPU_ERR_WITNESS = -8,    /* non-canonical field element (>= p) in the wire matrix, the public inputs or explicit salts */
+  QPGPU_ERR_VERIFY = -9      /* qpgpu_verify_batch: a proof was rejected (which and why: qpgpu_last_error) */
 } qpgpu_status;
 
 /* Gate tags = qp-plonky2's default gate-serializer ids as they appear in CommonCircuitData
@@ -121,6 +122,19 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
 int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wires, const uint64_t* const* public_inputs,
                       size_t num_public_inputs, const qpgpu_prove_opts* opts, uint8_t* out, size_t out_stride,
                       size_t* out_lens);
+
+/* ---- Verifier: VerifierCircuitData::verify as reached from WormholeVerifier::verify (wormhole/verifier/src/lib.rs:155-159), for a
+ * batch of proofs of one circuit (the aggregator takes in up to 512 leaf proofs, wormhole/aggregator/src/circuits/tree.rs:92-103).
+ * desc: the CommonCircuitData shape + circuit_digest (constants_sigmas is not needed and may be NULL); constants_sigmas_cap: the
+ * VerifierOnlyCircuitData cap, [2^cap_height][4] (qpgpu_parse_verifier_only reads both from verifier.bin). Leaf gate set only.
+ * Every Merkle opening is hashed on the device, the transcript and the field arithmetic run on host worker threads. */
+typedef struct qpgpu_verifier qpgpu_verifier;
+int qpgpu_verifier_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, const uint64_t* constants_sigmas_cap, qpgpu_verifier** out);
+void qpgpu_verifier_destroy(qpgpu_verifier* v);
+size_t qpgpu_verifier_proof_size(const qpgpu_verifier* v);
+/* proofs + i*proof_stride, each proof_len bytes of ProofWithPublicInputs::to_bytes(). results[i] = 0 (accepted) or QPGPU_ERR_VERIFY.
+ * Returns 0 if every proof was accepted, QPGPU_ERR_VERIFY if any was rejected, another negative status if the batch could not run. */
+int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_stride, size_t proof_len, size_t count, int32_t* results);
 
 #ifdef __cplusplus
 }

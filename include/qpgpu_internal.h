@@ -19,6 +19,10 @@ extern "C" {
  * fri_betas[2*layers] | pow_response | query indices[num_queries]. Returns the number of words written or a negative status. */
 int qpgpu_replay_transcript(const qpgpu_circuit_desc* desc, const uint8_t* proof, size_t len, uint64_t* out, size_t out_cap);
 
+/* Host half of qpgpu_verify_batch on ONE proof (transcript, proof of work, vanishing identity, FRI arithmetic, final polynomial;
+ * no Merkle openings, no device): 0 = these checks pass, QPGPU_ERR_VERIFY otherwise (reason in qpgpu_last_error). */
+int qpgpu_test_verify_host(const qpgpu_circuit_desc* desc, const uint8_t* proof, size_t len);
+
 /* ---- 2. profiling: HIP-event timers around kernel groups on the proving stream. mode 0 off, 1 dominant group only, 2 all groups. */
 void qpgpu_profile_enable(int mode);
 void qpgpu_profile_reset(void);

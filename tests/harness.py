@@ -18,6 +18,7 @@ u64p, u32p, u8p, ptr = _ffi.u64p, _ffi.u32p, _ffi.u8p, _ffi.ptr
 Gate, CircuitDesc, SynthParams, ProveOpts = _ffi.Gate, _ffi.CircuitDesc, _ffi.SynthParams, _ffi.ProveOpts
 qpgpu, synth, gpu_check, TEST_SALT_KEY = _ffi.qpgpu, _ffi.synth, _ffi.gpu_check, _ffi.TEST_SALT_KEY
 SynthCircuit, GpuCircuit, ReferenceCircuitShape, replay_transcript = _ffi.SynthCircuit, _ffi.GpuCircuit, _ffi.ReferenceCircuitShape, _ffi.replay_transcript
+GpuVerifier = _ffi.GpuVerifier
 
 
 def rand_felts(rng, shape):

@@ -1,0 +1,128 @@
+"""The product's batch verifier (include/qpgpu.h qpgpu_verify_batch, csrc/verify.hip) — the mirror of
+WormholeVerifier::verify (wormhole/verifier/src/lib.rs:155-159) and its tests (wormhole/tests/src/verifier/verifier_tests.rs:14-91):
+  * it accepts the reference's golden proof wormhole/bench-data/proof.bin given only common.bin + verifier.bin, with NO oracle in the loop:
+    the product's transcript, vanishing identity, FRI arithmetic and device Merkle kernels agree with bytes the Rust prover wrote;
+  * every public-input byte flip is rejected (verifier_tests.rs:49-66), and so is tampering anywhere in the proof body (the #[ignore]d
+    fuzz of :68-91, sampled);
+  * it agrees with the oracle verifier proof by proof on batches of device-made proofs with some of them corrupted."""
+import os, random
+import numpy as np
+import pytest
+from harness import *
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def blob(name):
+    return open(os.path.join(G, name), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def golden_verifier():
+    shape = ReferenceCircuitShape(blob("common.bin"), blob("verifier.bin")[:552])
+    v = GpuVerifier(shape.desc, shape.constants_sigmas_cap)
+    yield shape, v
+    v.close()
+
+
+def test_accepts_the_reference_golden_proof(golden_verifier):
+    shape, v = golden_verifier
+    pb = blob("proof.bin")
+    assert v.proof_size == len(pb) == 148932
+    assert v.verify(pb) is None
+    ok, msg = v.verify_batch([pb] * 5)
+    assert ok == [True] * 5 and msg is None
+
+
+def test_every_public_input_byte_flip_is_rejected(golden_verifier):          # verifier_tests.rs:49-66
+    shape, v = golden_verifier
+    pb = blob("proof.bin")
+    bad = []
+    for k in range(1, 16 * 8 + 1):
+        b = bytearray(pb); b[-k] ^= 0x01; bad.append(bytes(b))
+    ok, msg = v.verify_batch(bad)
+    assert not any(ok) and "rejected" in msg
+
+
+def test_tampering_anywhere_is_rejected_with_a_reason(golden_verifier):
+    shape, v = golden_verifier
+    pb = blob("proof.bin")
+    d = shape.desc
+    q0 = 3 * 512 + 4112 + 3 * 512                          # first query round (SURVEY.md App. B.3 size check)
+    cases = {
+        0: "vanishing",                                    # wires cap: changes beta/gamma -> the identity breaks
+        512 + 9: "vanishing", 1024 + 17: "vanishing",      # Z cap (alpha), quotient cap (zeta)
+        1536 + 5: "vanishing", 1536 + 4112 - 3: "vanishing",                      # openings
+        1536 + 4112 + 40: "proof of work|FRI|final",                              # a FRI layer cap (changes every later challenge)
+        q0 + 3: "FRI consistency", q0 + 84 * 8 + 1 + 40: "Merkle",                # a leaf value of oracle 0 (enters the combination), one of its siblings
+        q0 + 84 * 8: "length",                                                    # the u8 sibling count
+        q0 + 83 * 8 + 2: "FRI consistency|Merkle",                                # the last sigma column of that row
+        q0 + 3800 + 5: "FRI consistency|Merkle",                                  # a FRI layer evaluation
+        len(pb) - 128 - 8 - 8 - 64 + 3: "proof of work|final|FRI",                # final polynomial (observed before the PoW)
+        len(pb) - 128 - 8 - 8 + 2: "proof of work",                               # pow witness
+    }
+    import re
+    proofs, pats = [], []
+    for pos, pat in cases.items():
+        b = bytearray(pb); b[pos] ^= 0x04; proofs.append(bytes(b)); pats.append(pat)
+    for pf, pat in zip(proofs, pats):
+        msg = v.verify(pf)
+        assert msg is not None and re.search(pat, msg), (pat, msg)
+    ok, _ = v.verify_batch(proofs + [pb])
+    assert ok == [False] * len(proofs) + [True]
+    with pytest.raises(AssertionError):
+        v.verify_batch([pb, pb[:-8]])
+    ok, msg = v.verify_batch([pb[:-8]])
+    assert ok == [False] and "length" in msg
+
+
+def test_random_byte_flips_agree_with_the_oracle_verifier(golden_verifier):
+    shape, v = golden_verifier
+    pb = blob("proof.bin")
+    cb, vo = blob("common.bin"), blob("verifier.bin")[:552]
+    rnd = random.Random(2024)
+    proofs = []
+    for _ in range(48):
+        b = bytearray(pb); pos = rnd.randrange(len(pb)); b[pos] ^= 1 << rnd.randrange(8); proofs.append(bytes(b))
+    ok, _ = v.verify_batch(proofs)
+    L = oracle()
+    want = [L.orc_verify_bytes(cb, len(cb), vo, len(vo), p, len(p)) == 0 for p in proofs]
+    assert ok == want and not any(ok)
+
+
+@pytest.mark.parametrize("preset", ["T", "TZ", "A"])
+def test_batches_of_device_proofs_match_the_oracle_verdicts(preset):
+    sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+    v = GpuVerifier(sc.desc, gc.cap())
+    try:
+        nb = 12 if preset != "A" else 6
+        wits = [sc.witness(900 + i) for i in range(nb)]
+        proofs = gc.prove_batch([w for w, _ in wits], [p for _, p in wits], salt_seed=900)
+        ok, msg = v.verify_batch(proofs)
+        assert ok == [True] * nb and msg is None
+        rnd = random.Random(7)
+        mixed = []
+        for i, pf in enumerate(proofs):
+            if i % 3 == 1:
+                b = bytearray(pf); b[rnd.randrange(len(pf))] ^= 0x20; pf = bytes(b)
+            mixed.append(pf)
+        ok, msg = v.verify_batch(mixed)
+        want = [oc.verify(pf) is None for pf in mixed]
+        assert ok == want and ok.count(False) == len([i for i in range(nb) if i % 3 == 1])
+        # a witness that violates a gate still proves (as upstream) and both verifiers reject it
+        w, p = sc.witness(5); w = w.copy(); w[3, 1] = (int(w[3, 1]) + 1) % P
+        broken = gc.prove(w, p, salt_seed=5)
+        assert v.verify(broken) is not None and oc.verify(broken) is not None
+    finally:
+        v.close(); gc.close()
+
+
+def test_recursion_gate_circuits_are_refused():
+    sc = SynthCircuit("RT")
+    gc = GpuCircuit(sc.desc)
+    try:
+        with pytest.raises(RuntimeError, match="error -1.*leaf gate set"):
+            GpuVerifier(sc.desc, gc.cap())
+    finally:
+        gc.close()

@@ -59,3 +59,21 @@ def test_replay_is_sensitive_to_every_observed_section(shape):
             assert r[k] == base[k], (pos, k)
         for k in changed:
             assert r[k] != base[k], (pos, k)
+
+
+def test_host_half_of_the_product_verifier_accepts_the_golden_proof(shape):
+    """csrc/verify.hip's host half (transcript, vanishing identity with the leaf gate set over F_{p^2}, proof of work, FRI combination,
+    barycentric layer folds, final polynomial) on the reference's proof — every check except the Merkle openings, which are the
+    device half (tests/test_gpu_verifier.py). No oracle involved."""
+    L = qpgpu()
+    pb = blob("proof.bin")
+    assert L.qpgpu_test_verify_host(ctypes.byref(shape.desc), pb, len(pb)) == 0, L.qpgpu_last_error()
+    want = {5: b"vanishing", 512 + 5: b"vanishing", 1024 + 5: b"vanishing", 1536 + 77: b"vanishing", 1536 + 4112 - 1: b"vanishing",
+            len(pb) - 3: b"vanishing",                                        # a public input: pi_hash feeds the PublicInput gate and the transcript
+            len(pb) - 128 - 16 + 1: b"proof of work",
+            1536 + 4112 + 1536 + 5: b"FRI consistency",                       # first initial-tree row of query 0
+            1536 + 4112 + 1536 + 3800 + 9: b"FRI consistency"}                # first FRI layer evaluations of query 0
+    for pos, reason in want.items():
+        bad = bytearray(pb); bad[pos] ^= 0x02
+        assert L.qpgpu_test_verify_host(ctypes.byref(shape.desc), bytes(bad), len(bad)) == -9 and reason in L.qpgpu_last_error(), (pos, L.qpgpu_last_error())
+    assert L.qpgpu_test_verify_host(ctypes.byref(shape.desc), pb[:-1], len(pb) - 1) == -9

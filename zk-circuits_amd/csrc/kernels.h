@@ -4,6 +4,8 @@
 #include "gl.h"
 #include <hip/hip_runtime.h>
 
+struct qpgpu_ctx { int device; };     // include/qpgpu.h's opaque context
+
 namespace qp {
 
 // ---------------- NTT / LDE (ntt.hip) ----------------
@@ -69,6 +71,11 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
 void merkle_leaves_colmajor_mode(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, int mode, hipStream_t s);
 void merkle_level_mode(const u64* in, u64* out, size_t parents, int mode, hipStream_t s);
 void merkle_leaves_fri_mode(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, int mode, hipStream_t s);
+// Merkle openings (verifier): path p hashes its row (hash_or_noop of `width` felts at rows + p*width), climbs `depth` siblings
+// (sibs + (p*depth + l)*4) by the bits of idx[p] and compares with digest idx[p] >> depth of its cap: caps + cap_of[p] * 4 * 2^cap_h
+// (cap_of null: one shared cap). ok[p] = 1 on match.
+void verify_paths(const u64* rows, int width, const u64* sibs, int depth, const u32* idx, const u64* caps, const u32* cap_of, int cap_h,
+                  size_t num_paths, u32* ok, hipStream_t s);
 static inline size_t merkle_level_offset(size_t num_leaves, int level) {  // in digests
   size_t off = 0; for (int l = 0; l < level; l++) { off += num_leaves; num_leaves >>= 1; } return off;
 }

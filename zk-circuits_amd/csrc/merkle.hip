@@ -342,6 +342,48 @@ void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s
   }
 }
 
+// ---- verifier: one lane per Merkle opening (leaf sponge, then `depth` 2-to-1 steps up to the cap). All lanes of a launch share width
+// and depth, so waves stay converged; the openings of a batch of proofs give thousands of independent lanes.
+__global__ void __launch_bounds__(256) k_verify_paths(const u64* rows, int width, const u64* sibs, int depth, const u32* idx, const u64* caps,
+                                                      const u32* cap_of, int cap_h, size_t np, u32* ok) {
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const u64* row = rows + p * (size_t)width;
+  u64 st[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) st[k] = 0;
+  if (width <= 4) { for (int k = 0; k < width; k++) st[k] = row[k]; }
+  else {
+    for (int off = 0; off < width; off += 8) {
+      const int m = width - off < 8 ? width - off : 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k < m) st[k] = row[off + k];
+      poseidon_permute_dev(st);
+    }
+  }
+  u32 index = idx[p];
+  const u64* sb = sibs + p * (size_t)depth * 4;
+  for (int l = 0; l < depth; l++, sb += 4) {
+    const bool right = index & 1;                    // this node is the right child: the sibling goes first
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const u64 d = st[k], s2 = sb[k]; st[k] = right ? s2 : d; st[4 + k] = right ? d : s2; }
+#pragma unroll
+    for (int k = 8; k < 12; k++) st[k] = 0;
+    poseidon_permute_dev(st);
+    index >>= 1;
+  }
+  const u64* cap = caps + (((size_t)(cap_of ? cap_of[p] : 0)) << (cap_h + 2)) + (size_t)index * 4;
+  bool same = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) same = same && st[k] == cap[k];
+  ok[p] = same ? 1u : 0u;
+}
+void verify_paths(const u64* rows, int width, const u64* sibs, int depth, const u32* idx, const u64* caps, const u32* cap_of, int cap_h,
+                  size_t num_paths, u32* ok, hipStream_t s) {
+  if (!num_paths) return;
+  hipLaunchKernelGGL(k_verify_paths, dim3((unsigned)((num_paths + 255) / 256)), dim3(256), 0, s, rows, width, sibs, depth, idx, caps, cap_of, cap_h, num_paths, ok);
+}
+
 // ---- explicit kernel-form selection (kernels.h): one launch of the named form, whatever the size
 void merkle_leaves_colmajor_mode(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, int mode, hipStream_t s) {
   dim3 grid((unsigned)((num_leaves + 255) / 256));

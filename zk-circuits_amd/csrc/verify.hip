@@ -1,0 +1,429 @@
+// Batch proof verifier: qp-plonky2's VerifierCircuitData::verify as reached from WormholeVerifier::verify
+// (wormhole/verifier/src/lib.rs:155-159) and from the aggregator's self-checks (wormhole/aggregator/benches/aggregator.rs:62-101), for
+// many proofs of one circuit at a time — the shape the aggregator needs when it takes in 512 leaf proofs (BASELINE configs[3]).
+//
+// Split by where the work is (per B-sized proof: ~3.2 k Poseidon permutations of Merkle checking against ~0.1 k of transcript and a few
+// thousand extension-field operations):
+//   * device: every Merkle opening of every query of every proof (4 initial oracles + one tree per FRI layer), one lane per path,
+//     one launch per tree kind so that a wave's lanes run the same sponge length and path depth (k_verify_paths, merkle.hip);
+//   * host (worker threads over proofs): the Fiat-Shamir transcript (the prover's own Transcript, proof_format.h), the proof-of-work
+//     check, the vanishing identity at zeta with the leaf gate set evaluated over F_{p^2}, the FRI batch combination and the per-layer
+//     coset interpolation (barycentric over the multiplicative coset), the final-polynomial evaluation.
+// Formulas: SURVEY.md App. A.4-A.9 (validated there against wormhole/bench-data/*). Circuits with recursion-only gates are refused
+// (their extension-algebra forms at zeta are not restated here); lookups are not supported by this backend at all.
+#include "../../include/qpgpu_internal.h"
+#include "kernels.h"
+#include "options.h"
+#include "proof_format.h"
+#include <string>
+#include <vector>
+#include <thread>
+#include <atomic>
+#include <mutex>
+#include <cstring>
+#include <memory>
+
+namespace qp { extern thread_local std::string g_last_error; int set_err(int code, const std::string& m); }
+using namespace qp;
+
+struct qpgpu_verifier {
+  int device = 0;
+  qpgpu_circuit_desc d{}; std::vector<qpgpu_gate> gates; std::vector<uint32_t> sel_idx, groups; std::vector<u64> k_is, cap;
+  Layout lay{};
+  int log_n = 0, rate = 0, log_N = 0, cap_h = 0, nch = 0, S = 0, W = 0, Zp = 0, Q = 0, salt = 0, nlayers = 0, npp = 0;
+  int arity[MAX_FRI_LAYERS] = {0};
+  u64* d_cap = nullptr;
+  std::mutex mu;      // one batch at a time per handle (the staging buffers below are reused)
+  void* d_stage = nullptr; size_t d_stage_bytes = 0;
+};
+
+namespace {
+
+inline u64 rd64(const uint8_t* p) { u64 v; memcpy(&v, p, 8); return v >= GL_P ? v - GL_P : v; }     // plonky2 reads any u64 and works mod p
+inline Ext rdext(const uint8_t* p) { return ex(rd64(p), rd64(p + 8)); }
+inline Ext exb(u64 a) { return ex(a, 0); }
+inline Ext ex_small(Ext x, u64 c) { return ex(gl_mul(x.a, c), gl_mul(x.b, c)); }
+inline Ext ex_sq(Ext x) { return ex_mul(x, x); }
+inline Ext ex_sbox7(Ext x) { Ext x2 = ex_sq(x), x4 = ex_sq(x2), x3 = ex_mul(x2, x); return ex_mul(x3, x4); }
+
+void mds_ext(Ext st[12]) {
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  Ext out[12];
+  for (int r = 0; r < 12; r++) {
+    Ext acc = ex(0);
+    for (int i = 0; i < 12; i++) acc = ex_add(acc, ex_small(st[(i + r) % 12], C[i]));
+    if (r == 0) acc = ex_add(acc, ex_small(st[0], 8));
+    out[r] = acc;
+  }
+  for (int r = 0; r < 12; r++) st[r] = out[r];
+}
+
+// Gate constraints of the leaf gate set at the opening point: terms[j] += filter_g * c_{g,j}.
+// consts: the num_constants opened constant columns (selectors first); wires: the opened wire columns.
+void eval_leaf_gate_constraints(const qpgpu_verifier& v, const Ext* consts, const Ext* wires, const u64 pi_hash[4], std::vector<Ext>& terms) {
+  const qpgpu_circuit_desc& d = v.d;
+  const int nsel = (int)d.num_selector_groups;
+  const u64* rc = POSEIDON_RC_HOST;
+  for (uint32_t gi = 0; gi < d.num_gates; gi++) {
+    const qpgpu_gate& g = v.gates[gi];
+    const uint32_t si = v.sel_idx[gi], lo = v.groups[2 * si], hi = v.groups[2 * si + 1];
+    const Ext sv = consts[si];
+    Ext filter = ex(1);
+    for (uint32_t i = lo; i < hi; i++) if (i != gi) filter = ex_mul(filter, ex_sub(exb(i), sv));
+    if (nsel > 1) filter = ex_mul(filter, ex_sub(exb(0xFFFFFFFFULL), sv));
+    auto put = [&](size_t slot, Ext c) { terms[slot] = ex_add(terms[slot], ex_mul(filter, c)); };
+    switch (g.tag) {
+      case QPGPU_GATE_NOOP: break;
+      case QPGPU_GATE_CONSTANT:
+        for (u64 i = 0; i < g.param; i++) put(i, ex_sub(consts[nsel + i], wires[i]));
+        break;
+      case QPGPU_GATE_PUBLIC_INPUT:
+        for (int i = 0; i < 4; i++) put(i, ex_sub(wires[i], exb(pi_hash[i])));
+        break;
+      case QPGPU_GATE_BASESUM2: {
+        Ext sum = ex(0);
+        for (int l = (int)g.param - 1; l >= 0; l--) sum = ex_add(ex_add(sum, sum), wires[1 + l]);
+        put(0, ex_sub(sum, wires[0]));
+        for (u64 l = 0; l < g.param; l++) put(1 + l, ex_mul(wires[1 + l], ex_sub(wires[1 + l], ex(1))));
+        break;
+      }
+      case QPGPU_GATE_ARITHMETIC:
+        for (u64 i = 0; i < g.param; i++)
+          put(i, ex_sub(wires[4 * i + 3], ex_add(ex_mul(consts[nsel], ex_mul(wires[4 * i], wires[4 * i + 1])), ex_mul(consts[nsel + 1], wires[4 * i + 2]))));
+        break;
+      case QPGPU_GATE_POSEIDON: {
+        size_t k = 0;
+        const Ext swap = wires[24];
+        put(k++, ex_mul(swap, ex_sub(swap, ex(1))));
+        Ext st[12];
+        for (int i = 0; i < 4; i++) {
+          const Ext a = wires[i], b = wires[i + 4], delta = wires[25 + i];
+          put(k++, ex_sub(ex_mul(swap, ex_sub(b, a)), delta));
+          st[i] = ex_add(a, delta); st[i + 4] = ex_sub(b, delta);
+        }
+        for (int i = 8; i < 12; i++) st[i] = wires[i];
+        int round = 0;
+        auto add_rc = [&](int r) { for (int i = 0; i < 12; i++) st[i] = ex_add(st[i], exb(rc[12 * r + i])); };
+        for (int r = 0; r < 4; r++, round++) {                       // first full rounds: round 0's S-box inputs are not wired
+          add_rc(round);
+          if (r != 0) for (int i = 0; i < 12; i++) { const Ext in = wires[29 + 12 * (r - 1) + i]; put(k++, ex_sub(st[i], in)); st[i] = in; }
+          for (int i = 0; i < 12; i++) st[i] = ex_sbox7(st[i]);
+          mds_ext(st);
+        }
+        for (int r = 0; r < 22; r++, round++) {                      // partial rounds
+          add_rc(round);
+          const Ext in = wires[65 + r]; put(k++, ex_sub(st[0], in));
+          st[0] = ex_sbox7(in);
+          mds_ext(st);
+        }
+        for (int r = 0; r < 4; r++, round++) {                       // second full rounds
+          add_rc(round);
+          for (int i = 0; i < 12; i++) { const Ext in = wires[87 + 12 * r + i]; put(k++, ex_sub(st[i], in)); st[i] = in; }
+          for (int i = 0; i < 12; i++) st[i] = ex_sbox7(st[i]);
+          mds_ext(st);
+        }
+        for (int i = 0; i < 12; i++) put(k++, ex_sub(st[i], wires[12 + i]));
+        break;
+      }
+      default: break;    // refused at qpgpu_verifier_create
+    }
+  }
+}
+
+struct PathRef { const uint8_t* row; const uint8_t* sibs; u32 index; };   // one Merkle opening inside the proof bytes
+struct ProofWork {                                                        // what the host pass leaves for the device pass
+  std::string reason;                                                     // non-empty: already rejected on the host
+  std::vector<PathRef> paths[4 + MAX_FRI_LAYERS];
+};
+
+// Everything except the Merkle openings. Returns "" or the reason for rejection; fills w.paths with the openings to hash.
+std::string verify_host(const qpgpu_verifier& v, const uint8_t* pf, ProofWork& w) {
+  const qpgpu_circuit_desc& d = v.d; const Layout& L = v.lay;
+  const int nch = v.nch; const size_t capw = size_t(4) << v.cap_h, n = size_t(1) << v.log_n, N = size_t(1) << v.log_N;
+  { u64 npi; memcpy(&npi, pf + L.pis_off, 8); if (npi != d.num_public_inputs) return "public input count"; }
+  std::vector<u64> pis(d.num_public_inputs ? d.num_public_inputs : 1);
+  for (uint32_t i = 0; i < d.num_public_inputs; i++) pis[i] = rd64(pf + L.pis_off + 8 + 8 * (size_t)i);
+  u64 pi_hash[4]; hash_no_pad(pis.data(), d.num_public_inputs, pi_hash);
+  // ---- transcript (the same schedule the prover runs)
+  auto words = [&](size_t off, size_t cnt) { std::vector<u64> o(cnt); for (size_t i = 0; i < cnt; i++) o[i] = rd64(pf + off + 8 * i); return o; };
+  Transcript tr(nch);
+  u64 betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
+  { auto c = words(0, capw); tr.start((const u64*)d.circuit_digest, pi_hash, c.data(), capw, betas, gammas); }
+  { auto c = words(L.cap_bytes, capw); tr.after_zs_cap(c.data(), capw, alphas); }
+  Ext zeta; { auto c = words(2 * L.cap_bytes, capw); zeta = tr.after_quotient_cap(c.data(), capw); }
+  const size_t nop = L.n_openings;
+  std::vector<u64> opw = words(L.openings_off, 2 * nop);
+  const size_t a_ext = (size_t)v.S + v.W + nch, b_ext = (size_t)nch * v.npp + v.Q;
+  const Ext fri_alpha = tr.after_openings(opw.data(), a_ext, b_ext);
+  Ext fri_betas[MAX_FRI_LAYERS];
+  for (int l = 0; l < v.nlayers; l++) { auto c = words(L.fri_caps_off + (size_t)l * L.cap_bytes, capw); fri_betas[l] = tr.fri_layer_cap(c.data(), capw); }
+  std::vector<Ext> final_poly(L.final_poly_len);
+  for (size_t i = 0; i < L.final_poly_len; i++) { final_poly[i] = rdext(pf + L.final_poly_off + 16 * i); tr.final_poly_coeff(final_poly[i].a, final_poly[i].b); }
+  u64 pow_resp;
+  { u64 pw; memcpy(&pw, pf + L.pow_off, 8); pow_resp = tr.pow_response(pw >= GL_P ? pw - GL_P : pw); }
+  std::vector<u32> indices(d.fri_num_queries);
+  for (auto& x : indices) x = tr.query_index(N);
+  // ---- openings by name (proof order: constants|sigmas | wires | zs | zs_next | partial products | quotient)
+  std::vector<Ext> op(nop); for (size_t i = 0; i < nop; i++) op[i] = ex(opw[2 * i], opw[2 * i + 1]);
+  const Ext* o_cs = op.data(); const Ext* o_wires = o_cs + v.S; const Ext* o_zs = o_wires + v.W; const Ext* o_zs_next = o_zs + nch;
+  const Ext* o_pp = o_zs_next + nch; const Ext* o_q = o_pp + (size_t)nch * v.npp;
+  const Ext* o_sigmas = o_cs + d.num_constants;
+  // ---- vanishing identity at zeta (App. A.8)
+  {
+    std::vector<Ext> gate_terms(d.num_gate_constraints, ex(0));
+    eval_leaf_gate_constraints(v, o_cs, o_wires, pi_hash, gate_terms);
+    const Ext zeta_n = ex_pow(zeta, n), zh = ex_sub(zeta_n, ex(1));
+    const Ext l0 = ex_mul(zh, ex_inv(ex_small(ex_sub(zeta, ex(1)), (u64)n)));
+    std::vector<Ext> terms;
+    for (int c = 0; c < nch; c++) terms.push_back(ex_mul(l0, ex_sub(o_zs[c], ex(1))));
+    const int deg = (int)d.quotient_degree_factor, R = (int)d.num_routed;
+    for (int c = 0; c < nch; c++) {
+      int chunk = 0;
+      for (int j0 = 0; j0 < R; j0 += deg, chunk++) {
+        Ext num = ex(1), den = ex(1);
+        for (int j = j0; j < j0 + deg && j < R; j++) {
+          num = ex_mul(num, ex_add_base(ex_add(o_wires[j], ex_small(zeta, gl_mul(betas[c], v.k_is[j]))), gammas[c]));
+          den = ex_mul(den, ex_add_base(ex_add(o_wires[j], ex_small(o_sigmas[j], betas[c])), gammas[c]));
+        }
+        const Ext acc_lo = chunk == 0 ? o_zs[c] : o_pp[(size_t)c * v.npp + chunk - 1];
+        const Ext acc_hi = chunk == v.npp ? o_zs_next[c] : o_pp[(size_t)c * v.npp + chunk];
+        terms.push_back(ex_sub(ex_mul(acc_lo, num), ex_mul(acc_hi, den)));
+      }
+    }
+    terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
+    for (int c = 0; c < nch; c++) {
+      Ext van = ex(0); for (size_t i = terms.size(); i-- > 0;) van = ex_add(ex_small(van, alphas[c]), terms[i]);
+      Ext q = ex(0); for (int m = deg; m-- > 0;) q = ex_add(ex_mul(q, zeta_n), o_q[(size_t)c * deg + m]);
+      if (!ex_eq(van, ex_mul(zh, q))) return "vanishing identity (challenge " + std::to_string(c) + ")";
+    }
+  }
+  // ---- FRI (App. A.9): proof of work, reduced openings, then per query the initial combination, the layer folds and the final polynomial
+  { const int lz = pow_resp == 0 ? 64 : __builtin_clzll(pow_resp); if (lz < (int)d.fri_pow_bits) return "proof of work"; }
+  const size_t n0 = (size_t)v.S + v.W + v.Zp + v.Q;                 // polynomials opened at zeta, in oracle order
+  std::vector<Ext> apow(n0 + 1); apow[0] = ex(1); for (size_t i = 1; i <= n0; i++) apow[i] = ex_mul(apow[i - 1], fri_alpha);
+  Ext y0 = ex(0), y1 = ex(0);
+  { size_t j = 0;                                                    // batch 0 order = oracle order = proof order without zs_next
+    for (size_t i = 0; i < a_ext; i++, j++) y0 = ex_add(y0, ex_mul(op[i], apow[j]));
+    for (size_t i = a_ext + nch; i < nop; i++, j++) y0 = ex_add(y0, ex_mul(op[i], apow[j]));
+    for (int i = 0; i < nch; i++) y1 = ex_add(y1, ex_mul(o_zs_next[i], apow[i])); }
+  const Ext z0 = zeta, z1 = ex_small(zeta, gl_root(v.log_n));
+  const size_t widths[4] = {(size_t)v.S, (size_t)v.W + v.salt, (size_t)v.Zp + v.salt, (size_t)v.Q + v.salt};
+  const size_t unsalted[4] = {(size_t)v.S, (size_t)v.W, (size_t)v.Zp, (size_t)v.Q};
+  const size_t path = v.log_N - v.cap_h;
+  const u64 wN = gl_root(v.log_N);
+  for (uint32_t q = 0; q < d.fri_num_queries; q++) {
+    const uint8_t* p = pf + L.queries_off + (size_t)q * L.bytes_per_query;
+    u32 x_index = indices[q];
+    Ext sum0 = ex(0), sum1 = ex(0); size_t j = 0;
+    for (int t = 0; t < 4; t++) {
+      const uint8_t* row = p; p += 8 * widths[t];
+      if (*p != path) return "initial Merkle proof length (query " + std::to_string(q) + ")";
+      const uint8_t* sibs = p + 1; p += 1 + 32 * path;
+      w.paths[t].push_back(PathRef{row, sibs, x_index});
+      for (size_t k = 0; k < unsalted[t]; k++, j++) sum0 = ex_add(sum0, ex_small(apow[j], rd64(row + 8 * k)));
+      if (t == 2) for (int k = 0; k < nch; k++) sum1 = ex_add(sum1, ex_small(apow[k], rd64(row + 8 * (size_t)k)));
+    }
+    u64 sx = gl_mul(GL_GEN, gl_pow(wN, rev_bits(x_index, v.log_N)));
+    const Ext d0 = ex_sub(exb(sx), z0), d1 = ex_sub(exb(sx), z1);
+    if ((d0.a == 0 && d0.b == 0) || (d1.a == 0 && d1.b == 0)) return "opening point on the evaluation domain";
+    Ext old_eval = ex_mul(ex_sub(sum0, y0), ex_inv(d0));                               // sum = 0 * alpha^|batch 0| + ...
+    old_eval = ex_add(ex_mul(old_eval, apow[nch]), ex_mul(ex_sub(sum1, y1), ex_inv(d1)));
+    int lg = v.log_N;
+    for (int l = 0; l < v.nlayers; l++) {
+      const int ab = v.arity[l], m = 1 << ab;
+      const uint8_t* evals = p; p += (size_t)16 << ab;
+      const size_t fp = lg - ab - v.cap_h;
+      if (*p != fp) return "FRI Merkle proof length (query " + std::to_string(q) + ", layer " + std::to_string(l) + ")";
+      const uint8_t* sibs = p + 1; p += 1 + 32 * fp;
+      const u32 coset_index = x_index >> ab, within = x_index & (m - 1);
+      w.paths[4 + l].push_back(PathRef{evals, sibs, coset_index});
+      if (!ex_eq(rdext(evals + 16 * (size_t)within), old_eval)) return "FRI consistency (query " + std::to_string(q) + ", layer " + std::to_string(l) + ")";
+      // interpolate the coset {c g^i} -> evals[rev(i)] at beta, barycentric: P(b) = (b^m - c^m) / (m c^m) * sum_i y_i x_i / (b - x_i)
+      const u64 g = gl_root(ab);
+      const u64 c0 = gl_mul(sx, gl_pow(g, (u64)m - rev_bits(within, ab)));             // the coset's first point: sx * g^(-rev(within))
+      const Ext beta = fri_betas[l];
+      Ext acc = ex(0); u64 xi = c0; bool hit = false;
+      std::vector<Ext> den(m), pre(m + 1); pre[0] = ex(1);
+      for (int i = 0; i < m; i++) { den[i] = ex_sub(beta, exb(xi)); if (den[i].a == 0 && den[i].b == 0) hit = true; pre[i + 1] = ex_mul(pre[i], den[i]); xi = gl_mul(xi, g); }
+      if (hit) {                                                                       // beta on the coset (probability ~2^-120): the value is read off
+        xi = c0; for (int i = 0; i < m; i++) { if (ex_eq(beta, exb(xi))) old_eval = rdext(evals + 16 * (size_t)rev_bits(i, ab)); xi = gl_mul(xi, g); }
+      } else {
+        Ext inv = ex_inv(pre[m]);                                                      // Montgomery batch inversion of the m denominators
+        std::vector<u64> xs(m); xi = c0; for (int i = 0; i < m; i++) { xs[i] = xi; xi = gl_mul(xi, g); }
+        for (int i = m; i-- > 0;) {
+          const Ext di = ex_mul(inv, pre[i]); inv = ex_mul(inv, den[i]);
+          acc = ex_add(acc, ex_mul(ex_small(rdext(evals + 16 * (size_t)rev_bits(i, ab)), xs[i]), di));
+        }
+        const u64 cm = gl_pow(c0, (u64)m);
+        const Ext zb = ex_sub(ex_pow(beta, (u64)m), exb(cm));
+        old_eval = ex_mul(ex_small(zb, gl_inv(gl_mul((u64)m, cm))), acc);
+      }
+      for (int i = 0; i < ab; i++) sx = gl_sqr(sx);
+      x_index = coset_index; lg -= ab;
+    }
+    Ext fx = ex(0); for (size_t i = final_poly.size(); i-- > 0;) fx = ex_add(ex_small(fx, sx), final_poly[i]);
+    if (!ex_eq(fx, old_eval)) return "final polynomial (query " + std::to_string(q) + ")";
+  }
+  return "";
+}
+
+#define V_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(e_ == hipErrorOutOfMemory ? QPGPU_ERR_OOM : QPGPU_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <class F> int guard(F&& f) {
+  try { return f(); }
+  catch (const std::bad_alloc&) { return set_err(QPGPU_ERR_OOM, "host memory allocation failed"); }
+  catch (const std::exception& e) { return set_err(QPGPU_ERR_HIP, std::string("internal error: ") + e.what()); }
+  catch (...) { return set_err(QPGPU_ERR_HIP, "internal error"); }
+}
+
+} // namespace
+
+extern "C" {
+
+// validates the shape and fills the host side of a verifier (no device work)
+static int verifier_init_host(const qpgpu_circuit_desc* desc, const uint64_t* constants_sigmas_cap, qpgpu_verifier* v) {
+  const qpgpu_circuit_desc& d = *desc;
+  if (!d.gates || !d.selector_indices || !d.selector_group_ranges || !d.k_is) return set_err(QPGPU_ERR_ARG, "null array in the circuit descriptor");
+  if (d.degree_bits < 2 || d.degree_bits + d.fri_rate_bits > 28 || d.fri_rate_bits < 1) return set_err(QPGPU_ERR_ARG, "degree_bits / rate_bits out of range");
+  if (d.num_challenges < 1 || d.num_challenges > 2 || d.fri_num_layers > MAX_FRI_LAYERS || d.fri_num_queries > MAX_QUERIES || d.num_gates == 0 || d.num_gates > MAX_GATES)
+    return set_err(QPGPU_ERR_ARG, "unsupported circuit shape");
+  if (d.fri_cap_height > d.degree_bits + d.fri_rate_bits || d.fri_cap_height > 20 || d.num_routed > d.num_wires || d.num_selector_groups < 1 || d.num_constants < d.num_selector_groups)
+    return set_err(QPGPU_ERR_ARG, "unsupported circuit shape");
+  if ((d.num_partial_products + 1) * d.quotient_degree_factor < d.num_routed || d.quotient_degree_factor < 1) return set_err(QPGPU_ERR_ARG, "bad partial product count");
+  { uint32_t sum = 0, lg = d.degree_bits + d.fri_rate_bits;
+    for (uint32_t i = 0; i < d.fri_num_layers; i++) { const uint32_t a = d.fri_arity_bits[i]; if (a < 1 || a > 4) return set_err(QPGPU_ERR_ARG, "FRI arity bits must be 1..4"); sum += a;
+      if (lg < a + d.fri_cap_height) return set_err(QPGPU_ERR_ARG, "FRI layer tree smaller than its cap"); lg -= a; }
+    if (sum > d.degree_bits) return set_err(QPGPU_ERR_ARG, "FRI reductions exceed degree"); }
+  for (uint32_t i = 0; i < d.num_gates; i++) {
+    const qpgpu_gate& g = d.gates[i]; uint64_t ncons = 0;
+    switch (g.tag) {
+      case QPGPU_GATE_NOOP: break;
+      case QPGPU_GATE_CONSTANT: ncons = g.param; if (g.param + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants"); break;
+      case QPGPU_GATE_PUBLIC_INPUT: ncons = 4; break;
+      case QPGPU_GATE_BASESUM2: ncons = g.param + 1; if (g.param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires"); break;
+      case QPGPU_GATE_ARITHMETIC: ncons = g.param; if (4 * g.param > d.num_wires || d.num_selector_groups + 2 > d.num_constants) return set_err(QPGPU_ERR_ARG, "Arithmetic ops exceed wires"); break;
+      case QPGPU_GATE_POSEIDON: ncons = 123; if (d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires"); break;
+      default: return set_err(QPGPU_ERR_ARG, "the verifier handles the leaf gate set only (gate tag " + std::to_string(g.tag) + ")");
+    }
+    if (ncons > d.num_gate_constraints) return set_err(QPGPU_ERR_ARG, "num_gate_constraints smaller than a gate's constraint count");
+    if (d.selector_indices[i] >= d.num_selector_groups) return set_err(QPGPU_ERR_ARG, "selector index out of range");
+  }
+  for (uint32_t g = 0; g < d.num_selector_groups; g++) if (d.selector_group_ranges[2 * g] >= d.selector_group_ranges[2 * g + 1] || d.selector_group_ranges[2 * g + 1] > d.num_gates) return set_err(QPGPU_ERR_ARG, "selector group range");
+  v->d = d; v->gates.assign(d.gates, d.gates + d.num_gates); v->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
+  v->groups.assign(d.selector_group_ranges, d.selector_group_ranges + 2 * d.num_selector_groups); v->k_is.assign(d.k_is, d.k_is + d.num_routed);
+  v->d.gates = v->gates.data(); v->d.selector_indices = v->sel_idx.data(); v->d.selector_group_ranges = v->groups.data(); v->d.k_is = v->k_is.data(); v->d.constants_sigmas = nullptr;
+  v->log_n = d.degree_bits; v->rate = d.fri_rate_bits; v->log_N = v->log_n + v->rate; v->cap_h = d.fri_cap_height; v->nch = d.num_challenges;
+  v->S = d.num_constants + d.num_routed; v->W = d.num_wires; v->npp = d.num_partial_products; v->Zp = v->nch * (1 + v->npp); v->Q = v->nch * d.quotient_degree_factor;
+  v->salt = d.zero_knowledge ? 4 : 0; v->nlayers = d.fri_num_layers; for (int l = 0; l < v->nlayers; l++) v->arity[l] = d.fri_arity_bits[l];
+  compute_layout(d, v->lay);
+  const size_t capw = size_t(4) << v->cap_h;
+  v->cap.resize(capw); for (size_t i = 0; i < capw; i++) { if (constants_sigmas_cap[i] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical cap element"); v->cap[i] = constants_sigmas_cap[i]; }
+  return 0;
+}
+
+int qpgpu_verifier_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, const uint64_t* constants_sigmas_cap, qpgpu_verifier** out) { return guard([&]() -> int {
+  if (!ctx || !desc || !constants_sigmas_cap || !out) return set_err(QPGPU_ERR_ARG, "null argument");
+  std::unique_ptr<qpgpu_verifier> v(new qpgpu_verifier());
+  v->device = ctx->device;
+  { int rc = verifier_init_host(desc, constants_sigmas_cap, v.get()); if (rc) return rc; }
+  const size_t capw = size_t(4) << v->cap_h;
+  V_TRY(hipSetDevice(v->device));
+  V_TRY(hipMalloc((void**)&v->d_cap, capw * 8));
+  V_TRY(hipMemcpy(v->d_cap, v->cap.data(), capw * 8, hipMemcpyHostToDevice));
+  *out = v.release(); return 0;
+}); }
+
+// Host half of the verifier alone (include/qpgpu_internal.h): transcript, proof of work, vanishing identity, FRI arithmetic and final
+// polynomial of ONE proof, without the Merkle openings (those are the device half). 0 = these checks pass, QPGPU_ERR_VERIFY otherwise.
+int qpgpu_test_verify_host(const qpgpu_circuit_desc* desc, const uint8_t* proof, size_t len) { return guard([&]() -> int {
+  if (!desc || !proof) return set_err(QPGPU_ERR_ARG, "null argument");
+  qpgpu_verifier v;
+  std::vector<uint64_t> zero_cap((size_t(4) << (desc->fri_cap_height <= 20 ? desc->fri_cap_height : 0)), 0);
+  { int rc = verifier_init_host(desc, zero_cap.data(), &v); if (rc) return rc; }
+  if (len != v.lay.total) return set_err(QPGPU_ERR_VERIFY, "proof length");
+  ProofWork w;
+  const std::string r = verify_host(v, proof, w);
+  return r.empty() ? 0 : set_err(QPGPU_ERR_VERIFY, r);
+}); }
+
+void qpgpu_verifier_destroy(qpgpu_verifier* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->d_cap) (void)hipFree(v->d_cap);
+  if (v->d_stage) (void)hipFree(v->d_stage);
+  delete v;
+}
+
+size_t qpgpu_verifier_proof_size(const qpgpu_verifier* v) { return v ? v->lay.total : 0; }
+
+int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_stride, size_t proof_len, size_t count, int32_t* results) { return guard([&]() -> int {
+  if (!v || !proofs || !results) return set_err(QPGPU_ERR_ARG, "null argument");
+  if (count == 0) return 0;
+  if (proof_stride < proof_len) return set_err(QPGPU_ERR_ARG, "proof_stride smaller than proof_len");
+  std::lock_guard<std::mutex> lk(v->mu);
+  std::vector<ProofWork> work(count);
+  // ---- host pass: transcript, PoW, vanishing identity, FRI arithmetic (worker threads over proofs)
+  {
+    std::atomic<size_t> next(0);
+    auto body = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1); if (i >= count) break;
+        try {
+          if (proof_len != v->lay.total) work[i].reason = "proof length " + std::to_string(proof_len) + " != " + std::to_string(v->lay.total) + " for this circuit";
+          else work[i].reason = verify_host(*v, proofs + i * proof_stride, work[i]);
+        } catch (...) { work[i].reason = "internal error while parsing"; }
+      }
+    };
+    size_t nthreads = std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
+    std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
+    body(); for (auto& t : th) t.join();
+  }
+  // ---- device pass: all Merkle openings of the proofs that survived, one launch per tree kind
+  V_TRY(hipSetDevice(v->device));
+  const int kinds = 4 + v->nlayers;
+  const size_t widths[4] = {(size_t)v->S, (size_t)v->W + v->salt, (size_t)v->Zp + v->salt, (size_t)v->Q + v->salt};
+  std::vector<size_t> owner;                                       // path -> proof, per kind (rebuilt per kind)
+  for (int k = 0; k < kinds; k++) {
+    size_t width, depth; const u64* caps_dev = nullptr; size_t cap_off_bytes = 0; bool shared_cap = false;
+    if (k < 4) { width = widths[k]; depth = v->log_N - v->cap_h; shared_cap = k == 0; cap_off_bytes = (size_t)(k - 1) * v->lay.cap_bytes; }
+    else { const int l = k - 4; int lg = v->log_N; for (int i = 0; i < l; i++) lg -= v->arity[i]; width = (size_t)2 << v->arity[l]; depth = lg - v->arity[l] - v->cap_h; cap_off_bytes = v->lay.fri_caps_off + (size_t)l * v->lay.cap_bytes; }
+    owner.clear(); size_t live = 0;
+    for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) { live++; for (size_t j = 0; j < work[i].paths[k].size(); j++) owner.push_back(i); }
+    const size_t np = owner.size(); if (!np) continue;
+    // staging layout: rows [np][width] | sibs [np][depth][4] | caps [live][capn][4] (or the verifier's own cap) | idx [np] u32 | cap_of [np] u32 | ok [np] u32
+    const size_t capw = size_t(4) << v->cap_h;
+    const size_t rows_w = np * width, sibs_w = np * depth * 4, caps_w = shared_cap ? 0 : live * capw;
+    const size_t bytes = (rows_w + sibs_w + caps_w) * 8 + np * 12 + 64;
+    std::vector<u64> host((bytes + 7) / 8);
+    u64* h_rows = host.data(); u64* h_sibs = h_rows + rows_w; u64* h_caps = h_sibs + sibs_w;
+    u32* h_idx = (u32*)(h_caps + caps_w); u32* h_capof = h_idx + np;
+    { size_t p = 0, live_i = 0;
+      for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) {
+        if (!shared_cap) for (size_t c = 0; c < capw; c++) h_caps[live_i * capw + c] = rd64(proofs + i * proof_stride + cap_off_bytes + 8 * c);
+        for (const PathRef& pr : work[i].paths[k]) {
+          for (size_t c = 0; c < width; c++) h_rows[p * width + c] = rd64(pr.row + 8 * c);
+          for (size_t c = 0; c < depth * 4; c++) h_sibs[p * depth * 4 + c] = rd64(pr.sibs + 8 * c);
+          h_idx[p] = pr.index; h_capof[p] = (u32)live_i; p++;
+        }
+        live_i++;
+      } }
+    if (v->d_stage_bytes < bytes) { if (v->d_stage) (void)hipFree(v->d_stage); v->d_stage = nullptr; v->d_stage_bytes = 0; V_TRY(hipMalloc(&v->d_stage, bytes + bytes / 4)); v->d_stage_bytes = bytes + bytes / 4; }
+    V_TRY(hipMemcpy(v->d_stage, host.data(), (rows_w + sibs_w + caps_w) * 8 + np * 8, hipMemcpyHostToDevice));
+    u64* d_rows = (u64*)v->d_stage; u64* d_sibs = d_rows + rows_w; u64* d_caps = d_sibs + sibs_w; u32* d_idx = (u32*)(d_caps + caps_w); u32* d_capof = d_idx + np; u32* d_ok = d_capof + np;
+    caps_dev = shared_cap ? v->d_cap : d_caps;
+    verify_paths(d_rows, (int)width, d_sibs, (int)depth, d_idx, caps_dev, shared_cap ? nullptr : d_capof, v->cap_h, np, d_ok, 0);
+    V_TRY(hipGetLastError());
+    std::vector<u32> ok(np);
+    V_TRY(hipMemcpy(ok.data(), d_ok, np * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < np; p++) if (!ok[p] && work[owner[p]].reason.empty())
+      work[owner[p]].reason = (k < 4 ? "initial Merkle opening (oracle " + std::to_string(k) + ")" : "FRI Merkle opening (layer " + std::to_string(k - 4) + ")");
+  }
+  int rc = 0;
+  for (size_t i = 0; i < count; i++) {
+    results[i] = work[i].reason.empty() ? 0 : QPGPU_ERR_VERIFY;
+    if (!work[i].reason.empty() && rc == 0) rc = set_err(QPGPU_ERR_VERIFY, "proof " + std::to_string(i) + " rejected: " + work[i].reason);
+  }
+  return rc;
+}); }
+
+} // extern "C"

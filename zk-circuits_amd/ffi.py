@@ -104,8 +104,14 @@ def lib():
         L.qpgpu_parse_common.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(CircuitDesc), ctypes.POINTER(Gate), ctypes.c_size_t,
                                          u32p, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t]
         L.qpgpu_parse_verifier_only.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        L.qpgpu_verifier_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(CircuitDesc), u64p, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_verifier_destroy.argtypes = [ctypes.c_void_p]
+        L.qpgpu_verifier_proof_size.restype = ctypes.c_size_t
+        L.qpgpu_verifier_proof_size.argtypes = [ctypes.c_void_p]
+        L.qpgpu_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32)]
         # ---- include/qpgpu_internal.h
         L.qpgpu_replay_transcript.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t]
+        L.qpgpu_test_verify_host.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t]
         L.qpgpu_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.qpgpu_profile_name.restype = ctypes.c_char_p
         L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
@@ -287,6 +293,55 @@ class GpuCircuit:
         if self.h:
             L.qpgpu_circuit_destroy(self.h); self.h = None
         if self.ctx:
+            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuVerifier:
+    """qpgpu_verifier: VerifierCircuitData::verify for batches of proofs of one circuit (include/qpgpu.h). `cap` is the
+    constants/sigmas Merkle cap ([2^cap_height][4]); the descriptor needs no constants_sigmas."""
+
+    def __init__(self, desc, cap, device=0):
+        L = qpgpu()
+        self.desc = desc
+        self.ctx = ctypes.c_void_p()
+        gpu_check(L.qpgpu_ctx_create(device, ctypes.byref(self.ctx)))
+        cap = np.ascontiguousarray(cap, dtype=np.uint64)
+        self.h = ctypes.c_void_p()
+        rc = L.qpgpu_verifier_create(self.ctx, ctypes.byref(desc), ptr(cap), ctypes.byref(self.h))
+        if rc != 0:
+            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
+            gpu_check(rc)
+        self.proof_size = L.qpgpu_verifier_proof_size(self.h)
+
+    def verify_batch(self, proofs):
+        """Returns (results, message): results[i] is True for an accepted proof; message names the first rejection (or is None)."""
+        L = qpgpu()
+        k = len(proofs)
+        if k == 0:
+            return [], None
+        ln = len(proofs[0])
+        assert all(len(p) == ln for p in proofs), "one batch = proofs of one size"
+        res = (ctypes.c_int32 * k)()
+        rc = L.qpgpu_verify_batch(self.h, b"".join(proofs), ln, ln, k, res)
+        if rc not in (0, -9):
+            gpu_check(rc)
+        return [r == 0 for r in res], (L.qpgpu_last_error().decode() if rc else None)
+
+    def verify(self, proof):
+        ok, msg = self.verify_batch([proof])
+        return None if ok[0] else msg
+
+    def close(self):
+        L = qpgpu()
+        if getattr(self, "h", None):
+            L.qpgpu_verifier_destroy(self.h); self.h = None
+        if getattr(self, "ctx", None):
             L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
 
     def __del__(self):
