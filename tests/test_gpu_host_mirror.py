@@ -121,3 +121,27 @@ def test_cpp_host_mirror_example_runs():
         r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "proof bytes %d" % size in r.stdout and "second commit rejected: prover has already commited to inputs" in r.stdout
+
+
+def test_wormhole_verifier_mirror(pkg):
+    """verifier_tests.rs:14-66 against the mirror: verify OK for a proof of this prover; from the reference's verifier.bin / common.bin the
+    reference's own proof verifies; a flipped public input raises "proof verification failed"; bad artefact bytes are a ValueError."""
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rd = lambda n: open(os.path.join(G, n), "rb").read()
+    cfg = pkg.CircuitConfig.test_config(zero_knowledge=True)
+    prover = pkg.WormholeProver.new(cfg)
+    proof = prover.commit(pkg.CircuitInputs.test_inputs(2)).prove()
+    ver = pkg.WormholeVerifier.new(cfg)
+    ver.verify(proof)
+    bad = bytearray(proof.to_bytes()); bad[-1] ^= 1
+    with pytest.raises(RuntimeError, match="proof verification failed"):
+        ver.verify(bytes(bad))
+    ver.close()
+    ref = pkg.WormholeVerifier.new_from_bytes(rd("verifier.bin"), rd("common.bin"))      # the file as the reference writes it
+    ref.verify(rd("proof.bin"))
+    assert ref.verify_batch([rd("proof.bin"), rd("proof.bin")[:-8] + bytes(8)]) == [True, False]
+    ref.close()
+    with pytest.raises(ValueError, match="Failed to deserialize"):
+        pkg.WormholeVerifier.new_from_bytes(rd("verifier.bin")[:100], rd("common.bin"))
+    with pytest.raises(ValueError, match="Failed to deserialize"):
+        pkg.WormholeVerifier.new_from_bytes(rd("verifier.bin")[:552], rd("common.bin")[:-5])
