@@ -126,7 +126,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
 /* ---- Verifier: VerifierCircuitData::verify as reached from WormholeVerifier::verify (wormhole/verifier/src/lib.rs:155-159), for a
  * batch of proofs of one circuit (the aggregator takes in up to 512 leaf proofs, wormhole/aggregator/src/circuits/tree.rs:92-103).
  * desc: the CommonCircuitData shape + circuit_digest (constants_sigmas is not needed and may be NULL); constants_sigmas_cap: the
- * VerifierOnlyCircuitData cap, [2^cap_height][4] (qpgpu_parse_verifier_only reads both from verifier.bin). Leaf gate set only.
+ * VerifierOnlyCircuitData cap, [2^cap_height][4] (qpgpu_parse_verifier_only reads both from verifier.bin). Same gate set as the prover.
  * Every Merkle opening is hashed on the device, the transcript and the field arithmetic run on host worker threads. */
 typedef struct qpgpu_verifier qpgpu_verifier;
 int qpgpu_verifier_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, const uint64_t* constants_sigmas_cap, qpgpu_verifier** out);

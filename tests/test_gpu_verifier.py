@@ -118,11 +118,33 @@ def test_batches_of_device_proofs_match_the_oracle_verdicts(preset):
         v.close(); gc.close()
 
 
-def test_recursion_gate_circuits_are_refused():
-    sc = SynthCircuit("RT")
+def test_recursion_shaped_proofs_verify_too():
+    """The aggregation circuits' gate set (SURVEY.md App. D layouts, unpinned against Rust): device proofs of RT / RT2 are accepted, a
+    broken recursion-gate row and tampered bytes are rejected, verdicts equal the oracle's."""
+    for preset in ("RT", "RT2"):
+        sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)
+        v = GpuVerifier(sc.desc, gc.cap())
+        try:
+            wits = [sc.witness(40 + i) for i in range(6)]
+            proofs = gc.prove_batch([w for w, _ in wits], [p for _, p in wits])
+            pr = sc.params
+            row = 3 + pr.n_poseidon + pr.n_basesum + pr.n_arith + pr.n_constant + 2
+            w, p = sc.witness(9); w = w.copy(); w[6, row] = (int(w[6, row]) + 1) % P
+            proofs.append(gc.prove(w, p))
+            b = bytearray(proofs[0]); b[777] ^= 8; proofs.append(bytes(b))
+            ok, msg = v.verify_batch(proofs)
+            assert ok == [True] * 6 + [False, False] == [oc.verify(pf) is None for pf in proofs] and "rejected" in msg
+        finally:
+            v.close(); gc.close()
+
+
+def test_lookup_gates_are_refused():
+    sc = SynthCircuit("T")
     gc = GpuCircuit(sc.desc)
     try:
-        with pytest.raises(RuntimeError, match="error -1.*leaf gate set"):
-            GpuVerifier(sc.desc, gc.cap())
+        bad = CircuitDesc.from_buffer_copy(sc.desc)
+        bad.gates = (Gate * 6)(*[Gate(6 if i == 3 else sc.desc.gates[i].tag, 0, sc.desc.gates[i].param) for i in range(6)])
+        with pytest.raises(RuntimeError, match="error -1.*not supported"):
+            GpuVerifier(bad, gc.cap())
     finally:
         gc.close()

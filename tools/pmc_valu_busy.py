@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """VALU utilisation of the main kernels from PMC counters (run on the GPU box): one rocprofv3 pass per counter set
 (--pmc with --kernel-trace only). Reports per kernel: VALU instructions per wave, VALU-busy share of the kernel's GPU-active cycles."""
-import csv, glob, os, subprocess, sys
+import argparse, csv, glob, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser(); ap.add_argument("--preset", default="B"); ARGS = ap.parse_args()
 def run(counters, tag):
-    out = "gpurun_out/pmc_" + tag
+    out = "gpurun_out/pmc_busy_%s_%s" % (ARGS.preset, tag)
+    shutil.rmtree(os.path.join(ROOT, out), ignore_errors=True)          # one workload per directory
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
-           "python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipelined"]
+           "python3", "bench.py", "--preset", ARGS.preset, "--steps", "2" if ARGS.preset == "V" else "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipelined", "--no-tree"]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(env, QP_BENCH_SETTLE_S="0"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     if r.returncode != 0:
         print(tag, "failed:", r.stderr.decode()[-300:]); return {}
@@ -23,6 +25,7 @@ res = {}
 for cs, tag in sets:
     for k, v in run(cs, tag).items():
         res.setdefault(k, {}).update({c: x[1] / x[0] for c, x in v.items()})
+print("preset %s" % ARGS.preset)
 print("%-30s %12s %10s %14s %14s %12s" % ("kernel", "VALU/wave", "waves", "ACTIVE_VALU", "GUI_ACTIVE", "VALU issue %"))
 for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:12]:
     iv, wv = v.get("SQ_INSTS_VALU", 0), v.get("SQ_WAVES", 1)

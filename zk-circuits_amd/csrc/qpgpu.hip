@@ -716,7 +716,9 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     for (int i = 0; i < ch.n_in; i++) sp.s[i] = ch.in[i];
     const int pos = ch.n_in;
     u64 none = ~0ULL; pow_witness = none;
-    u64 base = 0, span = 1ULL << 17;
+    // first launch = the expected number of candidates (2^pow_bits: 63 % of proofs stop there), then doubling spans; the smallest valid
+    // witness wins whatever the span schedule (atomicMin over a range that is complete before the next one starts)
+    u64 base = 0, span = 1ULL << (d.fri_pow_bits < 12 ? 12 : (d.fri_pow_bits > 22 ? 22 : d.fri_pow_bits));
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
       { int rc_ = fetch_to_host(w, s, w->pow_result, 1); if (rc_) return rc_; }

@@ -9,8 +9,9 @@
 //   * host (worker threads over proofs): the Fiat-Shamir transcript (the prover's own Transcript, proof_format.h), the proof-of-work
 //     check, the vanishing identity at zeta with the leaf gate set evaluated over F_{p^2}, the FRI batch combination and the per-layer
 //     coset interpolation (barycentric over the multiplicative coset), the final-polynomial evaluation.
-// Formulas: SURVEY.md App. A.4-A.9 (validated there against wormhole/bench-data/*). Circuits with recursion-only gates are refused
-// (their extension-algebra forms at zeta are not restated here); lookups are not supported by this backend at all.
+// Formulas: SURVEY.md App. A.4-A.9 (validated there against wormhole/bench-data/*). The recursion-only gates of the aggregation circuits
+// are evaluated in upstream's extension algebra E[X]/(X^2-7) with the same (recalled, unpinned) layouts as the prover's kernel; lookups
+// are not supported by this backend at all.
 #include "../../include/qpgpu_internal.h"
 #include "kernels.h"
 #include "options.h"
@@ -32,6 +33,7 @@ struct qpgpu_verifier {
   Layout lay{};
   int log_n = 0, rate = 0, log_N = 0, cap_h = 0, nch = 0, S = 0, W = 0, Zp = 0, Q = 0, salt = 0, nlayers = 0, npp = 0;
   int arity[MAX_FRI_LAYERS] = {0};
+  u64 coset_w[16] = {0}, coset_dom[16] = {0};      // CosetInterpolation gate: barycentric weights and subgroup points
   u64* d_cap = nullptr;
   std::mutex mu;      // one batch at a time per handle (the staging buffers below are reused)
   void* d_stage = nullptr; size_t d_stage_bytes = 0;
@@ -45,6 +47,16 @@ inline Ext exb(u64 a) { return ex(a, 0); }
 inline Ext ex_small(Ext x, u64 c) { return ex(gl_mul(x.a, c), gl_mul(x.b, c)); }
 inline Ext ex_sq(Ext x) { return ex_mul(x, x); }
 inline Ext ex_sbox7(Ext x) { Ext x2 = ex_sq(x), x4 = ex_sq(x2), x3 = ex_mul(x2, x); return ex_mul(x3, x4); }
+
+// An extension-field wire pair (w0, w1) opened at zeta is an element w0 + w1*X of the algebra E[X]/(X^2 - 7) over E = F_{p^2}
+// (upstream's ExtensionAlgebra); on the prover's coset the same formulas run over the base field.
+struct Alg { Ext a, b; };
+inline Alg al(Ext a, Ext b) { Alg r; r.a = a; r.b = b; return r; }
+inline Alg al_add(Alg x, Alg y) { return al(ex_add(x.a, y.a), ex_add(x.b, y.b)); }
+inline Alg al_sub(Alg x, Alg y) { return al(ex_sub(x.a, y.a), ex_sub(x.b, y.b)); }
+inline Alg al_mul(Alg x, Alg y) { return al(ex_add(ex_mul(x.a, y.a), ex_small(ex_mul(x.b, y.b), 7)), ex_add(ex_mul(x.a, y.b), ex_mul(x.b, y.a))); }
+inline Alg al_scale(Alg x, Ext s) { return al(ex_mul(x.a, s), ex_mul(x.b, s)); }      // by a scalar of E (a constant column's opening)
+inline Alg al_small(Alg x, u64 c) { return al(ex_small(x.a, c), ex_small(x.b, c)); }  // by a base-field constant
 
 void mds_ext(Ext st[12]) {
   static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -123,6 +135,99 @@ void eval_leaf_gate_constraints(const qpgpu_verifier& v, const Ext* consts, cons
           mds_ext(st);
         }
         for (int i = 0; i < 12; i++) put(k++, ex_sub(st[i], wires[12 + i]));
+        break;
+      }
+      // ---- recursive-verifier circuit gates (layouts as in the prover's kernel, csrc/plonk.hip: parity with the
+      // Rust prover is unpinned for them, the verifier is consistent with this repo's prover and oracle)
+      case QPGPU_GATE_ARITHMETIC_EXTENSION:
+        for (u64 i = 0; i < g.param; i++) {
+          const Alg m0 = al(wires[8 * i], wires[8 * i + 1]), m1 = al(wires[8 * i + 2], wires[8 * i + 3]), ad = al(wires[8 * i + 4], wires[8 * i + 5]);
+          const Alg t = al_sub(al(wires[8 * i + 6], wires[8 * i + 7]), al_add(al_scale(al_mul(m0, m1), consts[nsel]), al_scale(ad, consts[nsel + 1])));
+          put(2 * i, t.a); put(2 * i + 1, t.b);
+        }
+        break;
+      case QPGPU_GATE_MUL_EXTENSION:
+        for (u64 i = 0; i < g.param; i++) {
+          const Alg m0 = al(wires[6 * i], wires[6 * i + 1]), m1 = al(wires[6 * i + 2], wires[6 * i + 3]);
+          const Alg t = al_sub(al(wires[6 * i + 4], wires[6 * i + 5]), al_scale(al_mul(m0, m1), consts[nsel]));
+          put(2 * i, t.a); put(2 * i + 1, t.b);
+        }
+        break;
+      case QPGPU_GATE_REDUCING:
+      case QPGPU_GATE_REDUCING_EXTENSION: {
+        const bool xc = g.tag == QPGPU_GATE_REDUCING_EXTENSION;
+        const size_t nc = g.param, start_accs = 6 + (xc ? 2 : 1) * nc;
+        const Alg alpha = al(wires[2], wires[3]);
+        Alg acc = al(wires[4], wires[5]);
+        for (size_t i = 0; i < nc; i++) {
+          const Alg coeff = xc ? al(wires[6 + 2 * i], wires[7 + 2 * i]) : al(wires[6 + i], ex(0));
+          const size_t ai = i == nc - 1 ? 0 : start_accs + 2 * i;
+          const Alg acc_i = al(wires[ai], wires[ai + 1]);
+          const Alg t = al_sub(al_add(al_mul(acc, alpha), coeff), acc_i);
+          put(2 * i, t.a); put(2 * i + 1, t.b);
+          acc = acc_i;
+        }
+        break;
+      }
+      case QPGPU_GATE_RANDOM_ACCESS: {
+        const int bits = (int)g.param, copies = (int)g.param2, extra = (int)g.param3, vec = 1 << bits;
+        const int routed = (2 + vec) * copies + extra;
+        size_t k = 0;
+        for (int c = 0; c < copies; c++) {
+          const int base = (2 + vec) * c;
+          Ext b[4], idx = ex(0), list[16];
+          for (int i = 0; i < bits; i++) { b[i] = wires[routed + c * bits + i]; put(k++, ex_mul(b[i], ex_sub(b[i], ex(1)))); }
+          for (int i = bits - 1; i >= 0; i--) idx = ex_add(ex_add(idx, idx), b[i]);
+          put(k++, ex_sub(idx, wires[base]));
+          for (int i = 0; i < vec; i++) list[i] = wires[base + 2 + i];
+          for (int lvl = 0; lvl < bits; lvl++)
+            for (int jj = 0; jj < (vec >> (lvl + 1)); jj++) list[jj] = ex_add(list[2 * jj], ex_mul(b[lvl], ex_sub(list[2 * jj + 1], list[2 * jj])));
+          put(k++, ex_sub(list[0], wires[base + 1]));
+        }
+        for (int i = 0; i < extra; i++) put(k++, ex_sub(consts[nsel + i], wires[(2 + vec) * copies + i]));
+        break;
+      }
+      case QPGPU_GATE_POSEIDON_MDS:
+        for (int h = 0; h < 2; h++) {                                // the small-constant MDS acts on the two coordinates independently
+          Ext st[12]; for (int i = 0; i < 12; i++) st[i] = wires[2 * i + h];
+          mds_ext(st);
+          for (int i = 0; i < 12; i++) put(2 * i + h, ex_sub(wires[24 + 2 * i + h], st[i]));
+        }
+        break;
+      case QPGPU_GATE_EXPONENTIATION: {
+        const size_t nb = g.param;
+        const Ext base = wires[0];
+        Ext prev = ex(1);
+        for (size_t i = 0; i < nb; i++) {
+          const Ext bit = wires[1 + (nb - 1 - i)], iv = wires[2 + nb + i];
+          put(i, ex_sub(ex_mul(prev, ex_add(ex_mul(bit, base), ex_sub(ex(1), bit))), iv));
+          prev = ex_sq(iv);
+        }
+        put(nb, ex_sub(wires[1 + nb], wires[2 + nb + nb - 1]));
+        break;
+      }
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        const int bits = (int)g.param, dg = (int)g.param2, np = 1 << bits, ni = (np - 2) / (dg - 1);
+        const int s_point = 1 + 2 * np, s_value = s_point + 2, s_inter = s_value + 2, s_shifted = s_inter + 4 * ni;
+        const Alg xs = al(wires[s_shifted], wires[s_shifted + 1]);
+        size_t k = 0;
+        { const Alg t = al_sub(al(wires[s_point], wires[s_point + 1]), al_scale(xs, wires[0])); put(k++, t.a); put(k++, t.b); }
+        Alg ev = al(ex(0), ex(0)), pr = al(ex(1), ex(0));
+        int lo2 = 0, hi2 = dg;
+        for (int seg = 0; seg <= ni; seg++) {
+          for (int i = lo2; i < hi2; i++) {
+            const Alg term = al(ex_sub(xs.a, exb(v.coset_dom[i])), xs.b);
+            const Alg val = al_small(al(wires[1 + 2 * i], wires[2 + 2 * i]), v.coset_w[i]);
+            ev = al_add(al_mul(ev, term), al_mul(val, pr)); pr = al_mul(pr, term);
+          }
+          if (seg == ni) break;
+          const Alg iev = al(wires[s_inter + 2 * seg], wires[s_inter + 2 * seg + 1]), ipr = al(wires[s_inter + 2 * (ni + seg)], wires[s_inter + 2 * (ni + seg) + 1]);
+          { const Alg t = al_sub(iev, ev); put(k++, t.a); put(k++, t.b); }
+          { const Alg t = al_sub(ipr, pr); put(k++, t.a); put(k++, t.b); }
+          ev = iev; pr = ipr;
+          lo2 = 1 + (dg - 1) * (seg + 1); hi2 = lo2 + dg - 1 < np ? lo2 + dg - 1 : np;
+        }
+        { const Alg t = al_sub(al(wires[s_value], wires[s_value + 1]), ev); put(k++, t.a); put(k++, t.b); }
         break;
       }
       default: break;    // refused at qpgpu_verifier_create
@@ -303,13 +408,34 @@ static int verifier_init_host(const qpgpu_circuit_desc* desc, const uint64_t* co
       case QPGPU_GATE_BASESUM2: ncons = g.param + 1; if (g.param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires"); break;
       case QPGPU_GATE_ARITHMETIC: ncons = g.param; if (4 * g.param > d.num_wires || d.num_selector_groups + 2 > d.num_constants) return set_err(QPGPU_ERR_ARG, "Arithmetic ops exceed wires"); break;
       case QPGPU_GATE_POSEIDON: ncons = 123; if (d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires"); break;
-      default: return set_err(QPGPU_ERR_ARG, "the verifier handles the leaf gate set only (gate tag " + std::to_string(g.tag) + ")");
+      case QPGPU_GATE_ARITHMETIC_EXTENSION: ncons = 2 * g.param; if (8 * g.param > d.num_routed || d.num_selector_groups + 2 > d.num_constants) return set_err(QPGPU_ERR_ARG, "ArithmeticExtension ops exceed routed wires"); break;
+      case QPGPU_GATE_MUL_EXTENSION: ncons = 2 * g.param; if (6 * g.param > d.num_routed || d.num_selector_groups + 1 > d.num_constants) return set_err(QPGPU_ERR_ARG, "MulExtension ops exceed routed wires"); break;
+      case QPGPU_GATE_REDUCING: ncons = 2 * g.param; if (g.param < 1 || 6 + 3 * g.param - 2 > d.num_wires) return set_err(QPGPU_ERR_ARG, "Reducing coefficients exceed wires"); break;
+      case QPGPU_GATE_REDUCING_EXTENSION: ncons = 2 * g.param; if (g.param < 1 || 6 + 4 * g.param - 2 > d.num_wires) return set_err(QPGPU_ERR_ARG, "ReducingExtension coefficients exceed wires"); break;
+      case QPGPU_GATE_RANDOM_ACCESS: {
+        if (g.param < 1 || g.param > 4) return set_err(QPGPU_ERR_ARG, "RandomAccess bits must be 1..4");
+        const uint64_t vec = 1ull << g.param, routed = (2 + vec) * g.param2 + g.param3;
+        if (routed > d.num_routed || routed + g.param * g.param2 > d.num_wires || g.param3 + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "RandomAccess copies exceed wires/constants");
+        ncons = (g.param + 2) * g.param2 + g.param3; break;
+      }
+      case QPGPU_GATE_POSEIDON_MDS: ncons = 24; if (d.num_wires < 48) return set_err(QPGPU_ERR_ARG, "PoseidonMds gate needs 48 wires"); break;
+      case QPGPU_GATE_EXPONENTIATION: ncons = g.param + 1; if (g.param < 1 || 2 + 2 * g.param > d.num_wires) return set_err(QPGPU_ERR_ARG, "Exponentiation bits exceed wires"); break;
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        if (g.param < 1 || g.param > 4 || g.param2 < 2 || !g.table || g.table_len != (1u << g.param)) return set_err(QPGPU_ERR_ARG, "CosetInterpolation needs subgroup_bits 1..4, degree >= 2 and 2^bits weights");
+        const uint64_t np = 1ull << g.param, ni = (np - 2) / (g.param2 - 1);
+        if (1 + 2 * np + 4 + 4 * ni + 2 > d.num_wires) return set_err(QPGPU_ERR_ARG, "CosetInterpolation exceeds wires");
+        for (uint32_t j = 0; j < i; j++) if (d.gates[j].tag == QPGPU_GATE_COSET_INTERPOLATION) return set_err(QPGPU_ERR_ARG, "one CosetInterpolation gate per circuit");
+        const u64 wg = gl_root((int)g.param); u64 x = 1;
+        for (uint32_t k = 0; k < g.table_len; k++) { if (g.table[k] >= GL_P) return set_err(QPGPU_ERR_ARG, "non-canonical barycentric weight"); v->coset_w[k] = g.table[k]; v->coset_dom[k] = x; x = gl_mul(x, wg); }
+        ncons = 4 + 4 * ni; break;
+      }
+      default: return set_err(QPGPU_ERR_ARG, "gate tag " + std::to_string(g.tag) + " is not supported by this backend (lookup gates)");
     }
     if (ncons > d.num_gate_constraints) return set_err(QPGPU_ERR_ARG, "num_gate_constraints smaller than a gate's constraint count");
     if (d.selector_indices[i] >= d.num_selector_groups) return set_err(QPGPU_ERR_ARG, "selector index out of range");
   }
   for (uint32_t g = 0; g < d.num_selector_groups; g++) if (d.selector_group_ranges[2 * g] >= d.selector_group_ranges[2 * g + 1] || d.selector_group_ranges[2 * g + 1] > d.num_gates) return set_err(QPGPU_ERR_ARG, "selector group range");
-  v->d = d; v->gates.assign(d.gates, d.gates + d.num_gates); v->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
+  v->d = d; v->gates.assign(d.gates, d.gates + d.num_gates); for (auto& gg : v->gates) gg.table = nullptr;   /* weights live in coset_w */ v->sel_idx.assign(d.selector_indices, d.selector_indices + d.num_gates);
   v->groups.assign(d.selector_group_ranges, d.selector_group_ranges + 2 * d.num_selector_groups); v->k_is.assign(d.k_is, d.k_is + d.num_routed);
   v->d.gates = v->gates.data(); v->d.selector_indices = v->sel_idx.data(); v->d.selector_group_ranges = v->groups.data(); v->d.k_is = v->k_is.data(); v->d.constants_sigmas = nullptr;
   v->log_n = d.degree_bits; v->rate = d.fri_rate_bits; v->log_N = v->log_n + v->rate; v->cap_h = d.fri_cap_height; v->nch = d.num_challenges;
