@@ -25,6 +25,12 @@ int main(int argc, char** argv) {
     std::printf("proof bytes %zu (second %zu), public inputs:", proof.to_bytes().size(), proof2.to_bytes().size());
     for (uint64_t x : proof.public_inputs) std::printf(" %016llx", (unsigned long long)x);
     std::printf("\n");
+    WormholeVerifier verifier(prover.circuit_data);                            // WormholeVerifier::new(config, Some(circuit_data))
+    verifier.verify(proof); verifier.verify(proof2);
+    ProofWithPublicInputs forged = proof; forged.bytes.back() ^= 1;            // verifier_tests.rs:49-66: a flipped public input must fail
+    auto verdicts = verifier.verify_batch({proof, forged, proof2});
+    std::printf("verified: %d %d %d\n", (int)verdicts[0], (int)verdicts[1], (int)verdicts[2]);
+    if (!verdicts[0] || verdicts[1] || !verdicts[2]) return 3;
     WormholeProofAggregator agg(TreeAggregationConfig(2, 1));
     agg.push_proof(proof); agg.push_proof(proof2);
     auto leaves = agg.aggregate(proof);

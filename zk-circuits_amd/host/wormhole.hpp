@@ -62,6 +62,7 @@ class CircuitData {                           // ProverCircuitData: resident on 
   CircuitData(const CircuitData&) = delete; CircuitData& operator=(const CircuitData&) = delete;
   const qpgpu_circuit_desc& common() const { return *desc_; }
   qpgpu_circuit* handle() const { return circuit_; }
+  qpgpu_ctx* context() const { return ctx_; }
   size_t proof_size() const { return qpgpu_proof_size(circuit_); }
   CircuitInputs test_inputs(uint64_t index = 0) const {     // CircuitInputs::test_inputs() analogue (seed 0x51570000 + index)
     CircuitInputs in; size_t n = size_t(1) << desc_->degree_bits;
@@ -105,6 +106,35 @@ class WormholeProver {
   std::shared_ptr<CircuitData> circuit_data;
  private:
   bool targets_; std::optional<CircuitInputs> witness_;
+};
+
+// wormhole/verifier/src/lib.rs:81-159 — VerifierCircuitData::verify through qpgpu_verify_batch (device Merkle openings, host algebra).
+class WormholeVerifier {
+ public:
+  explicit WormholeVerifier(std::shared_ptr<CircuitData> cd) : circuit_data(std::move(cd)) {     // WormholeVerifier::new(config, Some(data))
+    const auto& d = circuit_data->common();
+    std::vector<uint64_t> cap((size_t)4 << d.fri_cap_height);
+    if (qpgpu_circuit_constants_sigmas_cap(circuit_data->handle(), cap.data()) != 0) throw std::runtime_error(qpgpu_last_error());
+    if (qpgpu_verifier_create(circuit_data->context(), &d, cap.data(), &v_) != 0) throw std::runtime_error(qpgpu_last_error());
+  }
+  ~WormholeVerifier() { if (v_) qpgpu_verifier_destroy(v_); }
+  WormholeVerifier(const WormholeVerifier&) = delete; WormholeVerifier& operator=(const WormholeVerifier&) = delete;
+  void verify(const ProofWithPublicInputs& proof) const {                                          // lib.rs:155-159
+    int32_t res = 0;
+    if (qpgpu_verify_batch(v_, proof.bytes.data(), proof.bytes.size(), proof.bytes.size(), 1, &res) != 0)
+      throw std::runtime_error(std::string("proof verification failed: ") + qpgpu_last_error());
+  }
+  std::vector<bool> verify_batch(const std::vector<ProofWithPublicInputs>& proofs) const {         // one flag per proof, no throw for a rejected one
+    if (proofs.empty()) return {};
+    const size_t len = proofs[0].bytes.size(); std::vector<uint8_t> flat(len * proofs.size()); std::vector<int32_t> res(proofs.size());
+    for (size_t i = 0; i < proofs.size(); i++) { if (proofs[i].bytes.size() != len) throw std::runtime_error("one batch = proofs of one size"); memcpy(&flat[i * len], proofs[i].bytes.data(), len); }
+    const int rc = qpgpu_verify_batch(v_, flat.data(), len, len, proofs.size(), res.data());
+    if (rc != 0 && rc != QPGPU_ERR_VERIFY) throw std::runtime_error(qpgpu_last_error());
+    std::vector<bool> ok(proofs.size()); for (size_t i = 0; i < ok.size(); i++) ok[i] = res[i] == 0; return ok;
+  }
+  std::shared_ptr<CircuitData> circuit_data;
+ private:
+  qpgpu_verifier* v_ = nullptr;
 };
 
 struct TreeAggregationConfig {                 // circuits/tree.rs:32-55
