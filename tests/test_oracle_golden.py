@@ -196,3 +196,40 @@ def test_proof_size_formula_matches_goldens():
     b, a = SynthCircuit("B"), SynthCircuit("A")          # keep the owners alive: desc points into them
     assert GpuLayoutSize(b.desc) == 148932
     assert GpuLayoutSize(a.desc) == 132712
+
+
+@pytest.mark.parametrize("name", ["dummy_proof.bin", "dummy_proof_zk.bin"])
+def test_dummy_proof_merkle_openings_are_consistent(name):
+    """CPU twin of tests/test_gpu_golden_vectors.py::test_dummy_proof_merkle_openings_on_device: the oracle's hash recovers one leaf index
+    per query from the wires opening of the reference's dummy proofs, and the other openings reach their caps with it."""
+    from proof_format import parse_proof
+    L = oracle()
+    sc = SynthCircuit("A"); d = sc.desc
+    p = parse_proof(d, blob(name))
+
+    def h2(l, r):
+        o = np.zeros(4, dtype=np.uint64); L.orc_two_to_one(ptr(np.ascontiguousarray(l)), ptr(np.ascontiguousarray(r)), ptr(o)); return o
+
+    def leaf(row):
+        o = np.zeros(4, dtype=np.uint64); row = np.ascontiguousarray(row); L.orc_hash_or_noop(ptr(row), len(row), ptr(o)); return o
+    depth = d.degree_bits + d.fri_rate_bits - d.fri_cap_height
+    for q in p["queries"][:6]:                                           # six queries keep the pure-Python search in seconds
+        cand = [leaf(q["rows"][1])]
+        for lvl in range(depth):
+            sib = q["paths"][1][lvl]
+            cand = [h2(c, sib) for c in cand] + [h2(sib, c) for c in cand]
+        hits = [(c, j) for j in range(16) for c in range(len(cand)) if np.array_equal(cand[c], p["wires_cap"][j])]
+        assert len(hits) == 1
+        idx = hits[0][0] | (hits[0][1] << depth)
+        for t, cap in ((2, p["zs_cap"]), (3, p["quotient_cap"])):
+            dg, i = leaf(q["rows"][t]), idx
+            for lvl in range(depth):
+                dg = h2(q["paths"][t][lvl], dg) if i & 1 else h2(dg, q["paths"][t][lvl]); i >>= 1
+            assert np.array_equal(dg, cap[i])
+        sh = 0
+        for l in range(d.fri_num_layers):
+            sh += d.fri_arity_bits[l]
+            dg, i = leaf(q["layer_evals"][l].reshape(-1)), idx >> sh
+            for sib in q["layer_paths"][l]:
+                dg = h2(sib, dg) if i & 1 else h2(dg, sib); i >>= 1
+            assert np.array_equal(dg, p["fri_caps"][l][i])
