@@ -6,7 +6,7 @@ namespace qp {
 struct Options {
   int streams = 4;            // QPGPU_STREAMS: worker threads (one HIP stream + workspace each) of qpgpu_prove_batch
   int handoff_spin_us = -1;   // QPGPU_HANDOFF_SPIN_US: host busy-wait budget per device->host hand-off before it naps between polls
-                              //   (-1: 2000 us for single proofs, 50 us inside qpgpu_prove_batch workers)
+                              //   (-1: 2000 us; 50 us inside qpgpu_prove_batch workers when the process has fewer than two usable host cores per worker)
   int no_publish = 0;         // QPGPU_NO_PUBLISH=1: hipMemcpyAsync + hipStreamSynchronize instead of the publish kernel + mapped flag
   int timing = 0;             // QPGPU_TIMING=1: stage boundaries recorded with HIP events (qpgpu_last_stage_ms)
   int split_quotient = -1;    // QPGPU_SPLIT_QUOTIENT: -1 auto (split form for single proofs of leaf circuits), 0 fused kernel only, 1 split

@@ -23,6 +23,7 @@
 #include <memory>
 #include <chrono>
 #include <time.h>
+#include <sched.h>
 
 namespace qp {
 thread_local std::string g_last_error;
@@ -78,6 +79,7 @@ struct Workspace {
   bool shared_gpu = false;    // opt-in (QPGPU_SHARED_MODE=1): kernel choices that assume other proofs fill the chip
   bool pow_armed = false;     // pow_result[0] holds ~0 and pow_result[1] (the non-canonical-input flag) 0: re-armed by the last proof's gather kernel
   bool batch_mode = false;    // set for workers of qpgpu_prove_batch when several proofs share the chip: fused quotient kernel
+  bool cores_to_spare = true; // the process may use at least two host cores per batch worker: workers keep busy-polling their hand-offs
   u64 *wires_vals, *wires_coeffs, *wires_lde, *wires_dig, *zpp_scratch, *zs_vals, *zs_coeffs, *zs_lde, *zs_dig, *q_vals, *q_lde, *q_dig;
   u64 *alpha_pows, *zp0, *zp1, *zi0, *zi1, *openings, *open_partial, *comp0, *comp1, *compose_partial, *div_scratch, *pow_result;
   u64* fri_coeffs[MAX_FRI_LAYERS + 1]; u64* fri_vals[MAX_FRI_LAYERS]; u64* fri_dig[MAX_FRI_LAYERS];
@@ -196,6 +198,22 @@ static void ws_destroy(Workspace* w) {
   delete w;
 }
 
+// Host cores this process may use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of its cores).
+static int usable_cpus() {
+  static const int n = [] {
+    int k = (int)std::thread::hardware_concurrency();
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) k = a; }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64]; long long per = 0;
+      if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long long c = atoll(q) / per; if (c >= 1 && c < k) k = (int)c; }
+      fclose(f);
+    }
+    return k > 0 ? k : 1;
+  }();
+  return n;
+}
+
 // Brings `words` u64 from device memory to w->pinned and waits for them. Fast path: publish kernel + spin on the mapped flag;
 // fallback (no mapped pointer, or the flag does not arrive): copy + stream synchronise, which also surfaces kernel faults.
 // `extra` (optional) is one more device word, delivered at w->pinned[words].
@@ -209,7 +227,7 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
     const u64 seq = ++w->pub_seq;
     volatile u64* flag = w->pinned + w->pinned_elems;
     publish_to_host(src, w->pinned_dev, words, w->pinned_dev + w->pinned_elems, w->pub_counter, seq, s, extra, clear_extra);
-    const int budget_us = opts().handoff_spin_us >= 0 ? opts().handoff_spin_us : (w->batch_mode ? 50 : 2000);
+    const int budget_us = opts().handoff_spin_us >= 0 ? opts().handoff_spin_us : (w->batch_mode && !w->cores_to_spare ? 50 : 2000);
     const auto t0 = std::chrono::steady_clock::now();
     bool napping = false; uint64_t naps = 0;
     for (uint64_t spins = 0;; spins++) {
@@ -856,6 +874,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
     Workspace* w = nullptr; int rc = ws_acquire(c, &w);
     if (rc) { std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } return; }
     w->batch_mode = workers > 1;
+    w->cores_to_spare = usable_cpus() >= 2 * workers;      // busy-polling 4 workers on a 16-core share costs nothing and is 2-3 % faster than napping
     w->shared_gpu = qp::opts().shared_mode != 0;   // the batch-mode kernel choices stopped paying once the field arithmetic got cheaper (profiles/r01_notes_ab_experiments.md)
     for (;;) {
       size_t i = next.fetch_add(1); if (i >= batch || first_rc.load()) break;
@@ -865,7 +884,7 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
       if (rc) { (void)hipStreamSynchronize(w->stream); (void)hipStreamSynchronize(w->side); w->pev_used = 0; std::lock_guard<std::mutex> lk(emu); if (!first_rc) { first_rc = rc; emsg = g_last_error; } break; }
       if (out_lens) out_lens[i] = c->lay.total;
     }
-    w->shared_gpu = false; w->batch_mode = false;
+    w->shared_gpu = false; w->batch_mode = false; w->cores_to_spare = true;
     ws_release(c, w);
   };
   auto body = [&]() {

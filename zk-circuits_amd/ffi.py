@@ -3,6 +3,7 @@
 Nothing here touches oracle/ (that binding lives in oracle/binding.py, test infrastructure)."""
 import ctypes
 import os
+import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -56,6 +57,7 @@ TEST_SALT_KEY = bytes([0x51, 0x50, 0x2d, 0x74, 0x65, 0x73, 0x74, 0x2d, 0x73, 0x6
 
 
 _KEY_BUFS = {}
+_tls = threading.local()
 
 
 def set_salt_key(opts, key):
@@ -260,9 +262,12 @@ class GpuCircuit:
             wp = wires.ctypes.data
         else:
             wp = wires_dev_ptr
-        buf = ctypes.create_string_buffer(self.proof_size)
+        tl = _tls.__dict__
+        buf = tl.get("buf")
+        if buf is None or len(buf) < self.proof_size:               # one output buffer per calling thread, reused across proofs
+            buf = tl["buf"] = ctypes.create_string_buffer(self.proof_size)
         n = ctypes.c_size_t()
-        gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, self.proof_size, ctypes.byref(n)))
+        gpu_check(L.qpgpu_prove(self.h, wp, ptr(pis), len(pis), ctypes.byref(o), buf, len(buf), ctypes.byref(n)))
         return ctypes.string_at(buf, n.value)          # one copy (buf.raw[:n] makes two)
 
     def prove_batch(self, wires_list, pis_list, salt_seed=0, wires_on_device=False, salt_key=TEST_SALT_KEY):
