@@ -102,6 +102,17 @@ DEFK(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask
 DEFK(k_mix_mad_add, "v_mad_u64_u32 %8, vcc, %16, %17, %8\n v_add_u32 %0, %0, %16\n v_mad_u64_u32 %9, vcc, %16, %17, %9\n v_add_u32 %1, %1, %16\n"
                     "v_mad_u64_u32 %10, vcc, %16, %17, %10\n v_add_u32 %2, %2, %16\n v_mad_u64_u32 %11, vcc, %16, %17, %11\n v_add_u32 %3, %3, %16", "vcc")
 
+
+// ---- does the VALU-writes-SGPR -> VALU-reads-it hazard nop cost issue time? Each pair is a v_mad_u64_u32 with an SGPR carry-out and a
+// v_addc_co_u32 consuming it. A: consumer right behind its producer with the s_nop the compiler inserts; B: two pairs interleaved so that an
+// independent instruction sits in the gap (no nop needed); C: as A without the nop (wrong carries, timing reference only).
+DEFK(k_haz_nop, "v_mad_u64_u32 %8, s[20:21], %16, %17, %8\n s_nop 0\n v_addc_co_u32_e64 %0, s[20:21], %0, %16, s[20:21]\n v_mad_u64_u32 %9, s[22:23], %16, %17, %9\n s_nop 0\n v_addc_co_u32_e64 %1, s[22:23], %1, %16, s[22:23]\n"
+                "v_mad_u64_u32 %10, s[20:21], %16, %17, %10\n s_nop 0\n v_addc_co_u32_e64 %2, s[20:21], %2, %16, s[20:21]\n v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n s_nop 0\n v_addc_co_u32_e64 %3, s[22:23], %3, %16, s[22:23]", "s20", "s21", "s22", "s23")
+DEFK(k_haz_interleaved, "v_mad_u64_u32 %8, s[20:21], %16, %17, %8\n v_mad_u64_u32 %9, s[22:23], %16, %17, %9\n v_addc_co_u32_e64 %0, s[20:21], %0, %16, s[20:21]\n v_addc_co_u32_e64 %1, s[22:23], %1, %16, s[22:23]\n"
+                        "v_mad_u64_u32 %10, s[20:21], %16, %17, %10\n v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n v_addc_co_u32_e64 %2, s[20:21], %2, %16, s[20:21]\n v_addc_co_u32_e64 %3, s[22:23], %3, %16, s[22:23]", "s20", "s21", "s22", "s23")
+DEFK(k_haz_nonop, "v_mad_u64_u32 %8, s[20:21], %16, %17, %8\n v_addc_co_u32_e64 %0, s[20:21], %0, %16, s[20:21]\n v_mad_u64_u32 %9, s[22:23], %16, %17, %9\n v_addc_co_u32_e64 %1, s[22:23], %1, %16, s[22:23]\n"
+                  "v_mad_u64_u32 %10, s[20:21], %16, %17, %10\n v_addc_co_u32_e64 %2, s[20:21], %2, %16, s[20:21]\n v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n v_addc_co_u32_e64 %3, s[22:23], %3, %16, s[22:23]", "s20", "s21", "s22", "s23")
+
 struct Entry { const char* name; void (*k)(uint32_t*, unsigned long long*, uint32_t, uint32_t); };
 #define E(n) {#n, n}
 
@@ -111,7 +122,7 @@ int main() {
     E(k_mul_u32_u24), E(k_mul_hi_u32_u24), E(k_mad_u32_u24), E(k_mad_i32_i24), E(k_mul_lo_u32), E(k_mul_hi_u32), E(k_mad_u32_u16), E(k_dot2_u32_u16), E(k_dot4_u32_u8),
     E(k_dot8_u32_u4), E(k_dot2_i32_i16), E(k_dot4_i32_i8), E(k_pk_mad_u16), E(k_pk_mul_lo_u16), E(k_pk_add_u16), E(k_fma_f32), E(k_sad_u32), E(k_cndmask_vcc),
     E(k_mad_u64_u32), E(k_mad_u64_u32_sgprco), E(k_lshl_add_u64), E(k_lshlrev_b64), E(k_add_co_vcc), E(k_addc_co_vcc), E(k_add_co_sgpr), E(k_addc_co_sgpr), E(k_cndmask_sgpr),
-    E(k_cmp_lt_u32), E(k_fma_f64), E(k_pk_fma_f32), E(k_mov_dpp), E(k_mix_mad_add)};
+    E(k_cmp_lt_u32), E(k_fma_f64), E(k_pk_fma_f32), E(k_mov_dpp), E(k_mix_mad_add), E(k_haz_nop), E(k_haz_interleaved), E(k_haz_nonop)};
   uint32_t* d; unsigned long long* dc;
   const int max_blocks = 256 * 8;
   hipMalloc(&d, (size_t)max_blocks * 256 * 4); hipMalloc(&dc, (size_t)max_blocks * 4 * 8);
