@@ -409,7 +409,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
     if (t == QPGPU_GATE_POSEIDON && d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires");
     if (t == QPGPU_GATE_BASESUM2 && d.gates[i].param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires");
     if (t == QPGPU_GATE_ARITHMETIC && 4 * d.gates[i].param > d.num_wires) return set_err(QPGPU_ERR_ARG, "Arithmetic ops exceed wires");
-    if (t == QPGPU_GATE_CONSTANT && d.gates[i].param + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants");
+    if (t == QPGPU_GATE_CONSTANT && (d.gates[i].param + d.num_selector_groups > d.num_constants || d.gates[i].param > d.num_wires)) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants / wires");
   }
   HIP_TRY(hipSetDevice(ctx->device));
   struct CircuitGuard { qpgpu_circuit* p; ~CircuitGuard() { if (p) qpgpu_circuit_destroy(p); } } guard{new qpgpu_circuit()};   // freed (device memory too) on every early exit, exceptions included

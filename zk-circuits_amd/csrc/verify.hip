@@ -403,8 +403,8 @@ static int verifier_init_host(const qpgpu_circuit_desc* desc, const uint64_t* co
     const qpgpu_gate& g = d.gates[i]; uint64_t ncons = 0;
     switch (g.tag) {
       case QPGPU_GATE_NOOP: break;
-      case QPGPU_GATE_CONSTANT: ncons = g.param; if (g.param + d.num_selector_groups > d.num_constants) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants"); break;
-      case QPGPU_GATE_PUBLIC_INPUT: ncons = 4; break;
+      case QPGPU_GATE_CONSTANT: ncons = g.param; if (g.param + d.num_selector_groups > d.num_constants || g.param > d.num_wires) return set_err(QPGPU_ERR_ARG, "Constant gate exceeds constants / wires"); break;
+      case QPGPU_GATE_PUBLIC_INPUT: ncons = 4; if (d.num_wires < 4) return set_err(QPGPU_ERR_ARG, "PublicInput gate needs 4 wires"); break;
       case QPGPU_GATE_BASESUM2: ncons = g.param + 1; if (g.param + 1 > d.num_wires) return set_err(QPGPU_ERR_ARG, "BaseSum limbs exceed wires"); break;
       case QPGPU_GATE_ARITHMETIC: ncons = g.param; if (4 * g.param > d.num_wires || d.num_selector_groups + 2 > d.num_constants) return set_err(QPGPU_ERR_ARG, "Arithmetic ops exceed wires"); break;
       case QPGPU_GATE_POSEIDON: ncons = 123; if (d.num_wires < 135) return set_err(QPGPU_ERR_ARG, "Poseidon gate needs 135 wires"); break;
