@@ -36,6 +36,8 @@ void ntt_dif_noperm(u64* a, size_t n, const std::vector<u64>& tw /* w_n^j, j < n
 // holds coset c, exactly the layout upstream reaches with transpose + reverse_index_bits), produced column-major with
 // sequential writes and then transposed to rows in cache-sized tiles.
 Commitment commit_coeffs(std::vector<std::vector<u64>>&& coeffs, int rate_bits, int cap_height, const u64* salt /*[4][N] or null*/) {
+  const bool tmg = getenv("ORC_TIMING2") != nullptr; auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* nm) { if (!tmg) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "    [commit] %-12s %7.1f ms\n", nm, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
   Commitment cm; cm.coeffs = std::move(coeffs);
   size_t cols = cm.coeffs.size(), n = cm.coeffs[0].size(), N = n << rate_bits;
   int lgn = log2_exact(n), lgN = lgn + rate_bits; int s = salt ? 4 : 0;
@@ -46,6 +48,7 @@ Commitment commit_coeffs(std::vector<std::vector<u64>>&& coeffs, int rate_bits, 
   { u64 wN = gl_root(lgN);
 #pragma omp parallel for schedule(static)
     for (size_t c = 0; c < cosets; c++) { u64 base = gl_mul(GEN, gl_pow(wN, c)), x = 1; for (size_t i = 0; i < n; i++) { scale[c * n + i] = x; x = gl_mul(x, base); } } }
+  lap("alloc+scale");
   std::vector<u64> cm_lde(cols * N);
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
   for (size_t c = 0; c < cols; c++)
@@ -55,6 +58,7 @@ Commitment commit_coeffs(std::vector<std::vector<u64>>&& coeffs, int rate_bits, 
       for (size_t i = 0; i < n; i++) dst[i] = gl_mul(src[i], sc[i]);
       ntt_dif_noperm(dst, n, tw);
     }
+  lap("lde");
   const size_t TILE = 64;
 #pragma omp parallel for schedule(static)
   for (size_t L0 = 0; L0 < N; L0 += TILE) {
@@ -62,7 +66,9 @@ Commitment commit_coeffs(std::vector<std::vector<u64>>&& coeffs, int rate_bits, 
     for (size_t c = 0; c < cols; c++) { const u64* src = &cm_lde[c * N]; for (size_t L = L0; L < L1; L++) cm.rows[L * cm.width + c] = src[L]; }
     for (int k = 0; k < s; k++) for (size_t L = L0; L < L1; L++) cm.rows[L * cm.width + cols + k] = salt[(size_t)k * N + L];
   }
+  lap("transpose");
   cm.tree = merkle_build(cm.rows.data(), N, cm.width, cap_height);
+  lap("merkle");
   return cm;
 }
 
