@@ -30,9 +30,12 @@ thread_local std::string g_last_error;
 int set_err(int code, const std::string& m) { g_last_error = m; return code; }
 
 // ---- options (options.h): the one place that reads the environment
-static Options g_opts;
-const Options& opts() { return g_opts; }
+// Two buffers and an index: a refresh fills the inactive one and then flips, so readers racing with qpgpu_ctx_create see either the old
+// or the new set, never a half-written one.
+static Options g_opts[2]; static std::atomic<int> g_opts_cur(0); static std::mutex g_opts_mu;
+const Options& opts() { return g_opts[g_opts_cur.load(std::memory_order_acquire)]; }
 void options_refresh_from_env() {
+  std::lock_guard<std::mutex> lk(g_opts_mu);
   Options o;
   auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; };
   o.streams = geti("QPGPU_STREAMS", o.streams); o.handoff_spin_us = geti("QPGPU_HANDOFF_SPIN_US", o.handoff_spin_us);
@@ -43,7 +46,8 @@ void options_refresh_from_env() {
   o.pair_leaves = geti("QPGPU_PAIR_LEAVES", o.pair_leaves); o.pair_max = geti("QPGPU_PAIR_MAX", o.pair_max); o.coop_max = geti("QPGPU_COOP_MAX", o.coop_max);
   o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
-  g_opts = o;
+  const int nxt = 1 - g_opts_cur.load(std::memory_order_relaxed);
+  g_opts[nxt] = o; g_opts_cur.store(nxt, std::memory_order_release);
 }
 namespace { struct OptionsInit { OptionsInit() { options_refresh_from_env(); } } g_options_init; }
 }
