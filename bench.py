@@ -85,14 +85,23 @@ def main():
     # creation) are pointed at stderr, and the line goes to the saved descriptor at the end
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    # Rehearsal switches for a box with fewer GPUs than ranks (never used by the driver): QP_BENCH_BACKEND=gloo runs the collectives on CPU
+    # tensors (RCCL refuses two ranks on one device) and QP_BENCH_SHARE_GPU=1 maps rank r to device r % device_count.
+    backend = os.environ.get("QP_BENCH_BACKEND", "nccl")
+    if os.environ.get("QP_BENCH_SHARE_GPU"):
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1 or os.environ.get("QP_BENCH_FORCE_DIST"):      # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
     pinned = pin_to_gpu_numa_node(torch, local_rank)
 
     # ---- circuit (resident) + synthetic witnesses resident in HBM (outside the timed region)
@@ -150,7 +159,7 @@ def main():
     if dist is not None:
         # the first collective on a communicator connects the ranks and allocates its buffers (tens of ms): do one gather of the
         # same shape before the timed region, as a long-running aggregator would have
-        warm = torch.zeros(gc.proof_size * args.steps * args.batch, dtype=torch.uint8, device=dev)
+        warm = torch.zeros(gc.proof_size * args.steps * args.batch, dtype=torch.uint8, device=cdev)
         dist.all_gather([torch.empty_like(warm) for _ in range(world)], warm)
         del warm
     L.qpgpu_profile_reset()
@@ -161,14 +170,14 @@ def main():
     for i in range(args.steps):
         proofs += step(i)
     if dist is not None:
-        blob = torch.from_numpy(np.frombuffer(b"".join(proofs), dtype=np.uint8).copy()).to(dev)
+        blob = torch.from_numpy(np.frombuffer(b"".join(proofs), dtype=np.uint8).copy()).to(cdev)
         gathered = [torch.empty_like(blob) for _ in range(world)]
         dist.all_gather(gathered, blob)
     barrier()
     dt = time.perf_counter() - t0
     L.qpgpu_profile_enable(0)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -220,7 +229,7 @@ def main():
         barrier(); pdt = time.perf_counter() - t2
         to_check += [("pipelined_first", pp[0], 0, seeds[0]), ("pipelined_last", pp[-1], (nb - 1) % nwit, seeds[0] + nb - 1)]
         if dist is not None:
-            t = torch.tensor([pdt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); pdt = float(t.item())
+            t = torch.tensor([pdt], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX); pdt = float(t.item())
         pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
                      "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
 
@@ -246,7 +255,7 @@ def main():
             except Exception:
                 setup_ok = 0
             if dist is not None:                                  # all ranks enter the collectives below, or none does
-                t = torch.tensor([setup_ok], dtype=torch.int32, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); setup_ok = int(t.item())
+                t = torch.tensor([setup_ok], dtype=torch.int32, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN); setup_ok = int(t.item())
             if not setup_ok:
                 raise RuntimeError("aggregation-tree setup failed on a rank")
 
@@ -269,13 +278,13 @@ def main():
             leaf_proofs = gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)
             barrier(); t4 = time.perf_counter()
             if dist is not None:
-                root = agg.aggregate_to_tree_distributed(leaf_proofs, cfg, np_, lambda lvl: gc.proof_size if lvl == 0 else gcR.proof_size, device=dev)
+                root = agg.aggregate_to_tree_distributed(leaf_proofs, cfg, np_, lambda lvl: gc.proof_size if lvl == 0 else gcR.proof_size, device=(dev if backend == "nccl" else None))
             else:
                 root = agg.aggregate_to_tree(leaf_proofs, cfg, np_)
             barrier(); t5 = time.perf_counter()
             tl, tt = t4 - t3, t5 - t4
             if dist is not None:
-                t = torch.tensor([tl, tt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); tl, tt = float(t[0]), float(t[1])
+                t = torch.tensor([tl, tt], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX); tl, tt = float(t[0]), float(t[1])
             n_leaves = leaves_per_rank * world
             tree = {"leaves": n_leaves, "branching": 2, "levels": depth, "nodes": n_leaves - 1,
                     "leaf_stage_s": round(tl, 4), "leaf_proofs_per_s": round(n_leaves / tl, 1),
