@@ -19,6 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm maps a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); qpgpu_prove_batch's workers need one each to overlap.
+# Must be in the environment before the HIP runtime initialises (torch does that below), so it is set here, not in the library.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def available_cores():
@@ -218,7 +221,7 @@ def main():
     # ---- extra, NOT the headline: stream-pipelined throughput of independent proofs on this GPU (BASELINE configs[2] style)
     pipelined = None
     if args.batch == 1 and not args.no_pipelined:
-        nb = 16
+        nb = 32
         ptrs = [wit_dev[j % nwit].data_ptr() for j in range(nb)]
         pl = [pis_list[j % nwit] for j in range(nb)]
         gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)          # warm the per-stream workspaces
@@ -231,7 +234,7 @@ def main():
         if dist is not None:
             t = torch.tensor([pdt], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX); pdt = float(t.item())
         pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
-                     "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
+                     "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "8" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
 
     # ---- extra, NOT the headline: an aggregation tree over 64 leaves per GPU (BASELINE configs[2]/[3] flavour).
     # Leaves: one qpgpu_prove_batch of this preset. Nodes: level by level (tree.rs:56-103), every level one device batch of proofs of

@@ -4,7 +4,8 @@
 #pragma once
 namespace qp {
 struct Options {
-  int streams = 4;            // QPGPU_STREAMS: worker threads (one HIP stream + workspace each) of qpgpu_prove_batch
+  int streams = 4;            // QPGPU_STREAMS: worker threads (one HIP stream + workspace each) of qpgpu_prove_batch; default 8 when
+                              //   GPU_MAX_HW_QUEUES >= 8 (each worker needs hardware queues of its own to overlap), else 4
   int handoff_spin_us = -1;   // QPGPU_HANDOFF_SPIN_US: host busy-wait budget per device->host hand-off before it naps between polls
                               //   (-1: 2000 us; 50 us inside qpgpu_prove_batch workers when the process has fewer than two usable host cores per worker)
   int no_publish = 0;         // QPGPU_NO_PUBLISH=1: hipMemcpyAsync + hipStreamSynchronize instead of the publish kernel + mapped flag
