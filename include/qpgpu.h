@@ -101,6 +101,23 @@ int qpgpu_parse_common(const uint8_t* bytes, size_t len, qpgpu_circuit_desc* des
 /* VerifierOnlyCircuitData::to_bytes() (first 8 + 2^cap_height*32 + 32 bytes of `verifier.bin`): cap and circuit digest. */
 int qpgpu_parse_verifier_only(const uint8_t* bytes, size_t len, uint64_t* cap_out, size_t cap_words, uint64_t digest_out[4]);
 
+/* Writers, the inverse of the two parsers (what wormhole/circuit-builder/src/lib.rs:36-51 does with to_bytes()): byte-stable on the
+ * reference's bench-data/common.bin and verifier.bin. The CircuitConfig fields a descriptor does not carry are written with
+ * standard_recursion(_zk)_config's values (config.num_constants 2, security_bits 100, use_base_arithmetic_gate, FRI reduction strategy
+ * ConstantArityBits(4,5)). out == NULL queries the size (*len). */
+int qpgpu_write_common(const qpgpu_circuit_desc* desc, uint8_t* out, size_t cap, size_t* len);
+int qpgpu_write_verifier_only(const uint64_t* constants_sigmas_cap, uint32_t cap_height, const uint64_t circuit_digest[4],
+                              uint8_t* out, size_t cap, size_t* len);
+/* Circuit package: one blob with everything qpgpu_circuit_create needs — the common data in plonky2's byte format, the circuit digest and
+ * the constants/sigmas values — checksummed. It stands where prover.bin stands in the reference (wormhole/circuit-builder/src/lib.rs:53-63,
+ * loaded at wormhole/prover/src/lib.rs:105-137): ProverOnlyCircuitData's own layout is pinned by nothing the reference ships, and these
+ * values are all this backend needs from it. The descriptor of a read package points into the package and lives as long as it does. */
+typedef struct qpgpu_package qpgpu_package;
+int qpgpu_package_write(const qpgpu_circuit_desc* desc, uint8_t* out, size_t cap, size_t* len);
+int qpgpu_package_read(const uint8_t* bytes, size_t len, qpgpu_package** out);
+const qpgpu_circuit_desc* qpgpu_package_desc(const qpgpu_package* pkg);
+void qpgpu_package_free(qpgpu_package* pkg);
+
 /* Uploads the preprocessed columns, computes the constants/sigmas LDE + Merkle tree once and keeps it resident
  * (the work `builder.build_prover()` does at wormhole/circuit/src/circuit.rs:102-104). The handle is immutable and
  * may be shared by threads. */

@@ -19,6 +19,7 @@ Gate, CircuitDesc, SynthParams, ProveOpts = _ffi.Gate, _ffi.CircuitDesc, _ffi.Sy
 qpgpu, synth, gpu_check, TEST_SALT_KEY = _ffi.qpgpu, _ffi.synth, _ffi.gpu_check, _ffi.TEST_SALT_KEY
 SynthCircuit, GpuCircuit, ReferenceCircuitShape, replay_transcript = _ffi.SynthCircuit, _ffi.GpuCircuit, _ffi.ReferenceCircuitShape, _ffi.replay_transcript
 GpuVerifier = _ffi.GpuVerifier
+write_common, write_verifier_only, write_package, CircuitPackage = _ffi.write_common, _ffi.write_verifier_only, _ffi.write_package, _ffi.CircuitPackage
 
 
 def rand_felts(rng, shape):

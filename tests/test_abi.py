@@ -201,3 +201,33 @@ def test_salt_stream_is_chacha8():
         S.qpsynth_salt_block(bytes(range(32)), 9, idx // 8, ptr(out))
         assert int(flat[idx]) == int(out[idx % 8])
     assert np.array_equal(sc.salts(9), sc.salts_keyed(TEST_SALT_KEY, 9)) and int(flat.max()) < P
+
+
+def test_artefact_writers_are_byte_stable_on_the_reference_files():
+    """circuit_data_tests.rs:73-93 style: the reference's common.bin / verifier.bin parsed by the product and written back give the same bytes
+    (pins the writers — and through them the common data embedded in every circuit package — to reference data); packages round-trip, carry
+    the recursion gates' parameters and tables, and refuse corruption."""
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cb = open(os.path.join(G, "common.bin"), "rb").read(); vb = open(os.path.join(G, "verifier.bin"), "rb").read()
+    shape = ReferenceCircuitShape(cb, vb[:552])
+    assert write_common(shape.desc) == cb
+    assert write_verifier_only(shape.constants_sigmas_cap, 4, list(shape.desc.circuit_digest)) == vb[:552]
+    assert write_verifier_only(shape.constants_sigmas_cap, 4, list(shape.desc.circuit_digest)) + write_common(shape.desc) == vb   # bench-data layout (App. B.0)
+    for preset in ("T", "TZ", "RT", "RT2"):
+        sc = SynthCircuit(preset)
+        pk = write_package(sc.desc)
+        p = CircuitPackage(pk); d = p.desc
+        assert write_package(d) == pk and write_common(d) == write_common(sc.desc)
+        n = 1 << d.degree_bits; S = d.num_constants + d.num_routed
+        assert np.array_equal(np.ctypeslib.as_array(d.constants_sigmas, shape=(S, n)), sc.constants_sigmas())
+        assert list(d.circuit_digest) == list(sc.desc.circuit_digest)
+        for i in range(d.num_gates):
+            a, b = d.gates[i], sc.desc.gates[i]
+            assert (a.tag, a.param, a.param2, a.param3, a.table_len) == (b.tag, b.param, b.param2, b.param3, b.table_len)
+            assert [a.table[k] for k in range(a.table_len)] == [b.table[k] for k in range(b.table_len)]
+        for pos in (3, 40, len(pk) // 2, len(pk) - 1):
+            bad = bytearray(pk); bad[pos] ^= 1
+            with pytest.raises(RuntimeError, match="error -1"):
+                CircuitPackage(bytes(bad))
+        with pytest.raises(RuntimeError, match="error -1"):
+            CircuitPackage(pk[:-9])

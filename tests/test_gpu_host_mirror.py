@@ -160,3 +160,24 @@ def test_cpp_host_mirror_example(arg):
     assert "verified: 1 0 1" in r.stdout and "second commit rejected" in r.stdout
     size = 148932 if arg == "zk" else 132712                              # the reference's proof sizes
     assert "proof bytes %d (second %d)" % (size, size) in r.stdout
+
+
+def test_prove_and_verify_from_files(pkg, tmp_path):
+    """circuit_data_tests.rs:96-183: write the circuit artefacts, build prover and verifier from the files alone, prove and verify — and the
+    proof equals the one the in-memory circuit gives for the same witness."""
+    written = pkg.generate_circuit_binaries(str(tmp_path), include_prover=True, config=pkg.CircuitConfig.test_config())
+    assert set(written) == {"common.bin", "verifier.bin", "prover.qpkg"}
+    prover = pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin"))
+    src = pkg.WormholeCircuitData.get(pkg.CircuitConfig.test_config())
+    w, p = src.witness(0x51570003)
+    proof = prover.commit(pkg.CircuitInputs(wires=w, public_inputs=p)).prove()
+    ver = pkg.WormholeVerifier.new_from_files(str(tmp_path / "verifier.bin"), str(tmp_path / "common.bin"))
+    ver.verify(proof); ver.close()
+    again = pkg.WormholeProver(src).commit(pkg.CircuitInputs(wires=w, public_inputs=p)).prove()
+    assert proof.to_bytes() == again.to_bytes() == OracleCircuit(src.desc).prove(w, p)
+    with pytest.raises(ValueError, match="common circuit data"):
+        pkg.WormholeProver.new_from_bytes(open(tmp_path / "prover.qpkg", "rb").read(), open(tmp_path / "common.bin", "rb").read()[:-1])
+    with pytest.raises(ValueError, match="prover data"):
+        pkg.WormholeProver.new_from_bytes(b"not a package" * 10, b"")
+    with pytest.raises(RuntimeError, match="no synthetic witness source"):
+        pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin")).commit(pkg.CircuitInputs.test_inputs())

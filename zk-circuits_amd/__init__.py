@@ -13,5 +13,6 @@ from .ffi import lib, QpgpuError, CircuitDesc, ProveOpts, Gate  # noqa: F401
 from .prover import (CircuitConfig, CircuitInputs, ProofWithPublicInputs, WormholeProver,  # noqa: F401
                      WormholeCircuitData)
 from .verifier import WormholeVerifier  # noqa: F401
+from .circuit_builder import generate_circuit_binaries  # noqa: F401
 from .aggregator import (WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves, AggregatedProof,  # noqa: F401
                          aggregate_to_tree, aggregate_level, aggregate_to_tree_distributed, gather_proofs)

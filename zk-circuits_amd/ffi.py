@@ -106,6 +106,13 @@ def lib():
         L.qpgpu_parse_common.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(CircuitDesc), ctypes.POINTER(Gate), ctypes.c_size_t,
                                          u32p, u32p, ctypes.c_size_t, u64p, ctypes.c_size_t]
         L.qpgpu_parse_verifier_only.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        L.qpgpu_write_common.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_write_verifier_only.argtypes = [u64p, ctypes.c_uint32, u64p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_package_write.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpgpu_package_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_package_desc.restype = ctypes.POINTER(CircuitDesc)
+        L.qpgpu_package_desc.argtypes = [ctypes.c_void_p]
+        L.qpgpu_package_free.argtypes = [ctypes.c_void_p]
         L.qpgpu_verifier_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(CircuitDesc), u64p, ctypes.POINTER(ctypes.c_void_p)]
         L.qpgpu_verifier_destroy.argtypes = [ctypes.c_void_p]
         L.qpgpu_verifier_proof_size.restype = ctypes.c_size_t
@@ -303,6 +310,47 @@ class GpuCircuit:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+def _sized_write(fn, *args):
+    """Calls a qpgpu_*_write function twice: size query, then into a buffer of that size."""
+    n = ctypes.c_size_t()
+    gpu_check(fn(*args, None, 0, ctypes.byref(n)))
+    buf = ctypes.create_string_buffer(n.value)
+    gpu_check(fn(*args, buf, n.value, ctypes.byref(n)))
+    return buf.raw[:n.value]
+
+
+def write_common(desc):
+    """CommonCircuitData::to_bytes() of a descriptor (common.bin)."""
+    return _sized_write(qpgpu().qpgpu_write_common, ctypes.byref(desc))
+
+
+def write_verifier_only(cap, cap_height, digest):
+    """VerifierOnlyCircuitData::to_bytes(): cap height, constants/sigmas cap, circuit digest (verifier.bin as circuit-builder writes it)."""
+    cap = np.ascontiguousarray(cap, dtype=np.uint64); dg = np.ascontiguousarray(list(digest), dtype=np.uint64)
+    return _sized_write(qpgpu().qpgpu_write_verifier_only, ptr(cap), cap_height, ptr(dg))
+
+
+def write_package(desc):
+    """The circuit package of a descriptor that carries constants_sigmas (this backend's stand-in for prover.bin)."""
+    return _sized_write(qpgpu().qpgpu_package_write, ctypes.byref(desc))
+
+
+class CircuitPackage:
+    """A parsed circuit package: `desc` is ready for GpuCircuit / qpgpu_circuit_create and points into the package."""
+
+    def __init__(self, data):
+        self.h = ctypes.c_void_p()
+        gpu_check(qpgpu().qpgpu_package_read(bytes(data), len(data), ctypes.byref(self.h)))
+        self.desc = qpgpu().qpgpu_package_desc(self.h).contents
+
+    def __del__(self):
+        try:
+            if self.h:
+                qpgpu().qpgpu_package_free(self.h); self.h = None
         except Exception:
             pass
 

@@ -85,6 +85,35 @@ class WormholeCircuitData:
         self.proof_size = L.qpgpu_proof_size(self._circuit)
 
     @classmethod
+    def from_package(cls, package_bytes, device=0):
+        """Resident circuit from a circuit package (ffi.write_package / qpgpu_package_write) — the artefact path of
+        WormholeProver::new_from_bytes (wormhole/prover/src/lib.rs:105-137). No synthetic witness source: commit() needs an explicit witness."""
+        self = cls.__new__(cls)
+        self.config = None
+        self._package = ffi.CircuitPackage(package_bytes)       # owns the arrays desc points into
+        self._synth = None
+        self.desc = self._package.desc
+        self.n = 1 << self.desc.degree_bits
+        self.num_wires = self.desc.num_wires
+        self.num_public_inputs = self.desc.num_public_inputs
+        L = ffi.lib()
+        self._ctx = ctypes.c_void_p()
+        ffi.check(L.qpgpu_ctx_create(device, ctypes.byref(self._ctx)))
+        self._circuit = ctypes.c_void_p()
+        ffi.check(L.qpgpu_circuit_create(self._ctx, ctypes.byref(self.desc), ctypes.byref(self._circuit)))
+        self.proof_size = L.qpgpu_proof_size(self._circuit)
+        return self
+
+    def common_bytes(self):
+        return ffi.write_common(self.desc)
+
+    def verifier_only_bytes(self):
+        return ffi.write_verifier_only(self.constants_sigmas_cap(), self.desc.fri_cap_height, list(self.desc.circuit_digest))
+
+    def package_bytes(self):
+        return ffi.write_package(self.desc)
+
+    @classmethod
     def get(cls, config, device=0):
         key = (config.preset, device)
         if key not in cls._cache:
@@ -92,6 +121,8 @@ class WormholeCircuitData:
         return cls._cache[key]
 
     def witness(self, seed):
+        if self._synth is None:
+            raise RuntimeError("this circuit was loaded from a package: it has no synthetic witness source, commit an explicit witness")
         wires = np.zeros((self.num_wires, self.n), dtype=np.uint64)
         pis = np.zeros(self.num_public_inputs, dtype=np.uint64)
         ffi.synth_lib().qpsynth_witness(self._synth, seed, wires.ctypes.data_as(ffi.u64p), pis.ctypes.data_as(ffi.u64p))
@@ -133,6 +164,23 @@ class WormholeProver:
     @staticmethod
     def default(device=0):
         return WormholeProver.new(CircuitConfig.standard_recursion_zk_config(), device)
+
+    @staticmethod
+    def new_from_bytes(prover_only_bytes, common_bytes, device=0):
+        """wormhole/prover/src/lib.rs:105-137 with this backend's artefacts: `prover_only_bytes` is the circuit package that stands where
+        prover.bin stands, `common_bytes` the common.bin written next to it (it must be the common data embedded in the package). Malformed
+        input raises (the reference unwraps, lib.rs:128)."""
+        try:
+            cd = WormholeCircuitData.from_package(prover_only_bytes, device)
+        except ffi.QpgpuError as e:
+            raise ValueError("Failed to deserialize prover data from bytes: %s" % e)
+        if bytes(common_bytes) != cd.common_bytes():
+            raise ValueError("Failed to deserialize common circuit data from bytes: it is not the common data of this prover package")
+        return WormholeProver(cd)
+
+    @staticmethod
+    def new_from_files(prover_data_path, common_data_path, device=0):           # lib.rs:141-187
+        return WormholeProver.new_from_bytes(open(prover_data_path, "rb").read(), open(common_data_path, "rb").read(), device)
 
     def commit(self, circuit_inputs):
         if not self._targets:
