@@ -367,7 +367,8 @@ def main():
                                 "B": "single wormhole-shaped leaf proof, zk config, degree 2^14 (BASELINE configs[1])",
                                 "V": "voting-shaped proof at 2^20 rows (BASELINE configs[4])",
                                 "R": "recursion-shaped proof (all 14 gate types of the in-circuit verifier), non-zk, degree 2^13"}.get(args.preset, args.preset),
-                   "preset": args.preset, "proofs_per_step": args.batch, "degree_bits": int(sc.desc.degree_bits),
+                   "preset": args.preset, "proofs_per_step": args.batch,
+                   **({"batch_workload": "each step is one qpgpu_prove_batch of %d independent proofs, stream-pipelined on this GPU (BASELINE configs[2])" % args.batch} if args.batch > 1 else {}), "degree_bits": int(sc.desc.degree_bits),
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "host_cpus": pinned, "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
