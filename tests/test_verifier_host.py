@@ -58,3 +58,49 @@ def test_host_half_on_varied_fri_shapes(shape):
     assert host_verify(sc.desc, pf) is None
     bad = bytearray(pf); bad[len(pf) // 2] ^= 2
     assert oc.verify(bytes(bad)) is not None          # (the host half alone may pass it: mid-proof bytes are mostly Merkle siblings, the device half's job)
+
+
+def test_mutated_and_random_inputs_never_crash_the_host_side():
+    """Byte-level fuzz of everything in the product that parses untrusted bytes on the host: the verifier's host half (proof bytes), the
+    common / verifier-only parsers and the circuit-package reader. Every call must return a status (accepting is fine only for the
+    untouched input)."""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cb = open(os.path.join(G, "common.bin"), "rb").read(); vb = open(os.path.join(G, "verifier.bin"), "rb").read(); pb = open(os.path.join(G, "proof.bin"), "rb").read()
+    shape = ReferenceCircuitShape(cb, vb[:552])
+    L = qpgpu(); rnd = random.Random(77)
+    def mutate(b):
+        b = bytearray(b)
+        for _ in range(rnd.choice([1, 1, 2, 8, 64])):
+            pos = rnd.randrange(len(b))
+            b[pos] = rnd.choice([0, 0xFF, b[pos] ^ (1 << rnd.randrange(8)), rnd.randrange(256)])
+        return bytes(b)
+    accepted = 0
+    for _ in range(300):
+        m = mutate(pb)
+        rc = L.qpgpu_test_verify_host(ctypes.byref(shape.desc), m, len(m))
+        assert rc in (0, -9); accepted += rc == 0
+    assert accepted <= 220            # mutations that only hit Merkle siblings pass the host half (the device half catches them)
+    d = CircuitDesc(); gates = (Gate * 16)(); sel = (ctypes.c_uint32 * 16)(); grp = (ctypes.c_uint32 * 16)(); kis = (ctypes.c_uint64 * 160)()
+    cap = (ctypes.c_uint64 * 64)(); dig = (ctypes.c_uint64 * 4)()
+    for _ in range(500):
+        m = mutate(cb); cut = rnd.choice([len(m), len(m), rnd.randrange(len(m) + 1)])
+        assert L.qpgpu_parse_common(m[:cut], cut, ctypes.byref(d), gates, 16, sel, grp, 8, kis, 160) in (0, -1)
+        m = mutate(vb[:552]); cut = rnd.choice([len(m), rnd.randrange(len(m) + 1)])
+        assert L.qpgpu_parse_verifier_only(m[:cut], cut, cap, 64, dig) in (0, 1, 2, 3, 4, -1, -5)      # returns the cap height on success
+    sc = SynthCircuit("T")                            # keep the owner alive: desc points into it
+    pk = write_package(sc.desc)
+    ok = 0
+    for _ in range(200):
+        m = mutate(pk); cut = rnd.choice([len(m), len(m), rnd.randrange(len(m) + 1)])
+        h = ctypes.c_void_p()
+        rc = L.qpgpu_package_read(m[:cut], cut, ctypes.byref(h))
+        assert rc in (0, -1)
+        if rc == 0:
+            ok += 1; L.qpgpu_package_free(h)
+    assert ok == 0                                   # the checksum catches every mutation
+    for n in (0, 1, 7, 8, 100, 5000):
+        junk = bytes(rnd.randrange(256) for _ in range(n))
+        h = ctypes.c_void_p()
+        assert L.qpgpu_package_read(junk, n, ctypes.byref(h)) == -1
+        assert L.qpgpu_parse_common(junk, n, ctypes.byref(d), gates, 16, sel, grp, 8, kis, 160) == -1
