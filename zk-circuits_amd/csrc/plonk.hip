@@ -163,7 +163,7 @@ struct Zh8 { u64 zh[8]; u64 zh_inv[8]; };
 // their raw alpha-weighted sums to `out` ([nch][N]); k_quotient_sum adds the two and divides by Z_H. The halves are independent,
 // so a single proof runs them on two streams at once (each alone is only 2 waves/SIMD and stalls on its ~200-450 loads per point).
 template <int PART>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_quotient(CircuitDev cd, const u64* __restrict__ cs, const u64* __restrict__ wl,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_quotient(CircuitDev cd, const u64* __restrict__ cs, const u64* __restrict__ wl,
                                                   const u64* __restrict__ zl, Chal2 betas, Chal2 gammas,
                                                   const u64* __restrict__ apw, int ap_stride, Pi4 pih, Zh8 zh, u64 n_inv,
                                                   u64* __restrict__ out, const u64* __restrict__ rt, int log_M) {
