@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra (untimed-headline) stream-pipelined throughput measurement")
     ap.add_argument("--cpu-proofs", type=int, default=8)
     ap.add_argument("--no-tree", action="store_true", help="skip the extra aggregation-tree measurement (BASELINE configs[2]/[3] flavour)")
+    ap.add_argument("--no-real-circuit", action="store_true", help="skip the extra line on the wormhole circuit built by libqpcircuit (the reference's test inputs)")
     args = ap.parse_args()
 
     import importlib
@@ -236,6 +237,42 @@ def main():
         pipelined = {"proofs_per_s": round(reps * nb * world / pdt, 2), "ms_per_proof": round(pdt / (reps * nb) * 1e3, 4),
                      "batch": nb, "streams": int(os.environ.get("QPGPU_STREAMS", "8" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "4")), "note": "qpgpu_prove_batch: worker threads, one HIP stream + workspace each"}
 
+    # ---- extra, NOT the headline: the wormhole circuit itself (libqpcircuit: the reference's circuit definition on this repo's builder,
+    # include/qpcircuit.h) proving the reference's CircuitInputs::test_inputs(): host witness generation + device proof. Same statement and
+    # public inputs as the reference; gate placement is this builder's own, so the rows differ from the synthetic shape above.
+    real = None; real_check = None
+    if rank == 0 and args.batch == 1 and not args.no_real_circuit and args.preset in ("A", "B"):
+        try:
+            import importlib
+            ffi_ = importlib.import_module("zk-circuits_amd.ffi"); th_ = importlib.import_module("zk-circuits_amd.test_helpers")
+            inp_ = importlib.import_module("zk-circuits_amd.inputs")
+            zk_ = args.preset == "B"
+            t0_ = time.perf_counter(); bc = ffi_.BuiltCircuit(ffi_.QPC_WORMHOLE, zk_); build_s = time.perf_counter() - t0_
+            ci = th_.circuit_test_inputs()
+            reps_w = 20; t0_ = time.perf_counter()
+            for _ in range(reps_w):
+                w_, p_ = bc.witness(ci.fill_targets(), H.TEST_SALT_KEY)
+            wit_ms = (time.perf_counter() - t0_) / reps_w * 1e3
+            gcW = H.GpuCircuit(bc.desc, device=local_rank)
+            wd_ = torch.from_numpy(w_.view(np.int64)).to(dev); torch.cuda.synchronize()
+            for _ in range(3):
+                pfW = gcW.prove(None, p_, salt_seed=77, wires_dev_ptr=wd_.data_ptr())
+            reps_p = max(5, min(args.steps, 20)); t0_ = time.perf_counter()
+            for _ in range(reps_p):
+                pfW = gcW.prove(None, p_, salt_seed=77, wires_dev_ptr=wd_.data_ptr())
+            ms_ = (time.perf_counter() - t0_) / reps_p * 1e3
+            pub_ = inp_.PublicCircuitInputs.try_from_slice(np.frombuffer(pfW[-128:], dtype="<u8"))
+            real = {"circuit": "wormhole (libqpcircuit), %s" % ("standard_recursion_zk_config" if zk_ else "standard_recursion_config"),
+                    "inputs": "CircuitInputs::test_inputs() (wormhole/tests/test-helpers/src/lib.rs:25-59)", "degree_bits": int(bc.desc.degree_bits),
+                    "rows": bc.row_counts(), "build_circuit_s": round(build_s, 3), "witness_generation_ms": round(wit_ms, 3),
+                    "prove_ms": round(ms_, 4), "proofs_per_s": round(1e3 / ms_, 2), "proof_bytes": len(pfW),
+                    "public_inputs_match_prover_tests_rs": bool(pub_.funding_amount == 10 ** 12 and pub_.nullifier == ci.public.nullifier and pub_.root_hash == ci.public.root_hash),
+                    "note": "same statement / public inputs as the reference's circuit; rows, sigma and digest are this builder's own (parity unpinned)"}
+            real_check = (bc, w_, p_, pfW)
+            gcW.close()
+        except Exception as e:                                        # the extra must never take the headline down
+            real = {"error": repr(e)}
+
     # ---- extra, NOT the headline: an aggregation tree over 64 leaves per GPU (BASELINE configs[2]/[3] flavour).
     # Leaves: one qpgpu_prove_batch of this preset. Nodes: level by level (tree.rs:56-103), every level one device batch of proofs of
     # a recursion-shaped circuit (all 14 gate types, 2^13 rows). The node witnesses come from a small pre-generated pool picked by a hash
@@ -372,7 +409,7 @@ def main():
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "host_cpus": pinned, "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
-        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "aggregation_tree": tree, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "aggregation_tree": tree, "wormhole_circuit": real, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample
@@ -406,6 +443,10 @@ def main():
             bx["tree_leaves_verified"] = int(sum(1 for pf in tree_leaves if oc.verify(pf) is None))
             ocR = OracleCircuit(tree_desc_owner.desc)
             bx["tree_root_verified"] = bool(ocR.verify(tree_root) is None)
+        if real_check is not None:                                     # the real-circuit proof against the oracle's bytes for the same witness and salts
+            bc, w_, p_, pfW = real_check
+            ocW = OracleCircuit(bc.desc)
+            bx["wormhole_circuit"] = bool(pfW == ocW.prove(w_, p_, sc.salts(77) if bc.desc.zero_knowledge else None, threads=cores) and ocW.verify(pfW) is None)
         out["bit_exact_batch"] = bx
     if rank == 0:
         json_out.write(json.dumps(out) + "\n"); json_out.flush()

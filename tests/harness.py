@@ -22,6 +22,17 @@ GpuVerifier = _ffi.GpuVerifier
 write_common, write_verifier_only, write_package, CircuitPackage = _ffi.write_common, _ffi.write_verifier_only, _ffi.write_package, _ffi.CircuitPackage
 
 
+BuiltCircuit, CircuitError, circuit_lib = _ffi.BuiltCircuit, _ffi.CircuitError, _ffi.circuit_lib
+QPC_WORMHOLE, QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_VOTE = range(6)
+
+
+def check_witness(oc, wires, pis):
+    """Oracle check of a full witness: every gate constraint on every row and every copy constraint (sigma). None or the failure."""
+    L = oracle(); L.orc_check_witness.argtypes = [ctypes.c_void_p, u64p, u64p]
+    rc = L.orc_check_witness(oc.h, ptr(wires), ptr(pis))
+    return None if rc == 0 else L.orc_last_error().decode()
+
+
 def rand_felts(rng, shape):
     """Seeded canonical field elements, with edge values sprinkled in."""
     a = rng.integers(0, P, size=shape, dtype=np.uint64)

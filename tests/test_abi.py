@@ -8,7 +8,7 @@ from harness import *
 
 def declared_symbols(header):
     src = open(os.path.join(ROOT, "include", header)).read()
-    return sorted(set(re.findall(r"\b(qp(?:gpu|synth)_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(qp(?:gpu|synth|c|w|v)_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -20,6 +20,20 @@ def test_library_exports_every_declared_symbol():
     S = ctypes.CDLL(os.path.join(PKG, "libqpsynth.so"))
     for s in declared_symbols("qpsynth.h"):
         assert hasattr(S, s), s
+
+
+def test_circuit_library_exports_exactly_its_header():
+    """libqpcircuit.so (host-only: circuits + witness generation) exports include/qpcircuit.h, nothing else, and links neither the GPU
+    library nor the oracle."""
+    import subprocess
+    so = os.path.join(PKG, "libqpcircuit.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and not l.split()[2].startswith("_Z")}
+    declared = set(declared_symbols("qpcircuit.h"))
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert {"qpc_circuit_build", "qpc_generate_witness", "qpw_fill_targets", "qpv_fill_targets"} <= declared
+    ldd = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "liboracle" not in ldd and "libqpgpu" not in ldd and "amdhip" not in ldd
 
 
 def test_library_exports_nothing_undeclared():
@@ -112,7 +126,7 @@ def test_prover_commit_is_single_use_without_gpu():
     p = pkg.WormholeProver.__new__(pkg.WormholeProver)
     p.circuit_data = None; p._targets = False; p._witness = None
     with pytest.raises(RuntimeError, match="already commited"):                             # prover/src/lib.rs:210-212
-        p.commit(pkg.CircuitInputs.test_inputs())
+        p.commit(pkg.SyntheticInputs.test_inputs())
     with pytest.raises(RuntimeError, match="Failed to prove"):
         p.prove()
 

@@ -17,7 +17,7 @@ def pkg():
 def test_commit_and_prove(pkg):                                  # prover_tests.rs:14-18
     cfg = pkg.CircuitConfig.test_config()
     prover = pkg.WormholeProver.new(cfg)
-    proof = prover.commit(pkg.CircuitInputs.test_inputs()).prove()
+    proof = prover.commit(pkg.SyntheticInputs.test_inputs()).prove()
     assert len(proof) == prover.circuit_data.proof_size
     oc = OracleCircuit(prover.circuit_data.desc)
     assert oc.verify(proof.to_bytes()) is None
@@ -28,9 +28,9 @@ def test_commit_and_prove(pkg):                                  # prover_tests.
 
 def test_prover_is_single_use(pkg):                              # lib.rs:210-212
     prover = pkg.WormholeProver.new(pkg.CircuitConfig.test_config())
-    prover.commit(pkg.CircuitInputs.test_inputs(1))
+    prover.commit(pkg.SyntheticInputs.test_inputs(1))
     with pytest.raises(RuntimeError, match="already commited"):
-        prover.commit(pkg.CircuitInputs.test_inputs(2))
+        prover.commit(pkg.SyntheticInputs.test_inputs(2))
     prover.prove()
     with pytest.raises(RuntimeError, match="Failed to prove"):
         prover.prove()
@@ -38,7 +38,7 @@ def test_prover_is_single_use(pkg):                              # lib.rs:210-21
 
 def test_zk_config_prover(pkg):
     prover = pkg.WormholeProver.new(pkg.CircuitConfig.test_config(zero_knowledge=True))
-    proof = prover.commit(pkg.CircuitInputs.test_inputs(3)).prove()
+    proof = prover.commit(pkg.SyntheticInputs.test_inputs(3)).prove()
     oc = OracleCircuit(prover.circuit_data.desc)
     assert oc.verify(proof.to_bytes()) is None
 
@@ -46,7 +46,7 @@ def test_zk_config_prover(pkg):
 def test_aggregator_leaf_batch_and_padding(pkg):                 # aggregator_tests.rs: push / aggregate / leaf public inputs
     cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.test_config())
     agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, 2))
-    agg.prove_leaves([pkg.CircuitInputs.test_inputs(i) for i in range(3)])
+    agg.prove_leaves([pkg.SyntheticInputs.test_inputs(i) for i in range(3)])
     res = agg.aggregate()
     assert res.num_real == 3 and len(res.proofs) == 4
     oc = OracleCircuit(cd.desc)
@@ -82,7 +82,7 @@ def test_aggregation_tree_with_device_chunk_prover(pkg):          # tree.rs:56-1
 
     def run():
         agg = pkg.WormholeProofAggregator(cd, cfg)
-        agg.prove_leaves([pkg.CircuitInputs.test_inputs(i) for i in range(3)])      # 3 real leaves + 1 dummy
+        agg.prove_leaves([pkg.SyntheticInputs.test_inputs(i) for i in range(3)])      # 3 real leaves + 1 dummy
         return agg.aggregate(chunk_prover=chunk_prover)
 
     try:
@@ -130,7 +130,7 @@ def test_wormhole_verifier_mirror(pkg):
     rd = lambda n: open(os.path.join(G, n), "rb").read()
     cfg = pkg.CircuitConfig.test_config(zero_knowledge=True)
     prover = pkg.WormholeProver.new(cfg)
-    proof = prover.commit(pkg.CircuitInputs.test_inputs(2)).prove()
+    proof = prover.commit(pkg.SyntheticInputs.test_inputs(2)).prove()
     ver = pkg.WormholeVerifier.new(cfg)
     ver.verify(proof)
     bad = bytearray(proof.to_bytes()); bad[-1] ^= 1
@@ -170,14 +170,14 @@ def test_prove_and_verify_from_files(pkg, tmp_path):
     prover = pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin"))
     src = pkg.WormholeCircuitData.get(pkg.CircuitConfig.test_config())
     w, p = src.witness(0x51570003)
-    proof = prover.commit(pkg.CircuitInputs(wires=w, public_inputs=p)).prove()
+    proof = prover.commit(pkg.SyntheticInputs(wires=w, public_inputs=p)).prove()
     ver = pkg.WormholeVerifier.new_from_files(str(tmp_path / "verifier.bin"), str(tmp_path / "common.bin"))
     ver.verify(proof); ver.close()
-    again = pkg.WormholeProver(src).commit(pkg.CircuitInputs(wires=w, public_inputs=p)).prove()
+    again = pkg.WormholeProver(src).commit(pkg.SyntheticInputs(wires=w, public_inputs=p)).prove()
     assert proof.to_bytes() == again.to_bytes() == OracleCircuit(src.desc).prove(w, p)
     with pytest.raises(ValueError, match="common circuit data"):
         pkg.WormholeProver.new_from_bytes(open(tmp_path / "prover.qpkg", "rb").read(), open(tmp_path / "common.bin", "rb").read()[:-1])
     with pytest.raises(ValueError, match="prover data"):
         pkg.WormholeProver.new_from_bytes(b"not a package" * 10, b"")
     with pytest.raises(RuntimeError, match="no synthetic witness source"):
-        pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin")).commit(pkg.CircuitInputs.test_inputs())
+        pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin")).commit(pkg.SyntheticInputs.test_inputs())

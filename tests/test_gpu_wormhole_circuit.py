@@ -1,0 +1,114 @@
+"""The built wormhole / vote circuits (libqpcircuit, include/qpcircuit.h) through the HIP prover on a real GPU: the reference's
+prover tests (wormhole/tests/src/prover/prover_tests.rs:14-47), circuit-data round trip (circuit/circuit_data_tests.rs:96-183), leaf
+aggregation inputs (aggregator/aggregator_tests.rs) and the vote end-to-end test (voting/src/lib.rs:345-361) with CircuitInputs::test_inputs().
+
+Checked: GPU proof bytes == oracle prover bytes on the same witness and salts; the product verifier and the oracle verifier accept; the
+proof's public inputs are the values prover_tests.rs:29-43 expects. The circuit's rows/sigma/digest are this builder's own (unpinned)."""
+import importlib, json, os
+import numpy as np
+import pytest
+from harness import *
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("zk-circuits_amd")
+th = importlib.import_module("zk-circuits_amd.test_helpers")
+KATS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.json")))
+EXPECTED = dict(funding_amount=1_000_000_000_000, nullifier=bytes(KATS["expected_nullifier_bytes"]), root_hash=bytes(KATS["expected_root_hash_bytes"]),
+                exit_account=bytes([4] * 32))
+
+
+def _expected(pub):
+    return (pub.funding_amount, bytes(pub.nullifier), bytes(pub.root_hash), bytes(pub.exit_account)) == tuple(EXPECTED.values())
+
+
+@pytest.mark.parametrize("zk", [False, True])
+def test_gpu_proof_of_the_wormhole_circuit_is_byte_equal_to_the_oracle(zk):
+    c = BuiltCircuit(QPC_WORMHOLE, zk)
+    w, p = c.witness(th.circuit_test_inputs().fill_targets(), bytes(range(32)))
+    oc, gc = OracleCircuit(c.desc), GpuCircuit(c.desc)
+    assert np.array_equal(gc.cap(), oc.cap())
+    salts = SynthCircuit("B").salts_keyed(TEST_SALT_KEY, 11) if zk else None
+    got, want = gc.prove(w, p, salt_seed=11), oc.prove(w, p, salts=salts)
+    assert got == want and len(got) == (148932 if zk else 132712)
+    assert oc.verify(got) is None
+    v = GpuVerifier(c.desc, gc.cap())
+    assert v.verify(got) is None
+    bad = bytearray(got); bad[-8 * 16] ^= 1                                   # another nullifier: rejected
+    assert v.verify(bytes(bad)) is not None
+    v.close(); gc.close()
+
+
+def test_commit_and_prove_with_the_reference_inputs():           # prover_tests.rs:14-47
+    prover = pkg.WormholeProver.new(pkg.CircuitConfig.standard_recursion_config())
+    proof = prover.commit(th.circuit_test_inputs()).prove()
+    assert len(proof) == 132712
+    assert _expected(pkg.PublicCircuitInputs.try_from_proof(proof))
+    pkg.WormholeVerifier.new(pkg.CircuitConfig.standard_recursion_config()).verify(proof)
+    with pytest.raises(RuntimeError, match="already commited"):
+        prover.commit(th.circuit_test_inputs())
+
+
+def test_default_prover_is_the_zk_wormhole_circuit():             # WormholeProver::default (lib.rs:80-85): zk config, k = 14
+    prover = pkg.WormholeProver.default()
+    assert prover.circuit_data.desc.degree_bits == 14 and prover.circuit_data.desc.zero_knowledge == 1
+    a = prover.commit(th.circuit_test_inputs()).prove()
+    b = pkg.WormholeProver.default().commit(th.circuit_test_inputs()).prove()
+    assert len(a) == 148932 and _expected(pkg.PublicCircuitInputs.try_from_proof(a))
+    assert a.to_bytes() != b.to_bytes()                           # fresh blinding rows and salts per proof
+    v = pkg.WormholeVerifier.new(pkg.CircuitConfig.standard_recursion_zk_config())
+    assert v.verify_batch([a, b]) == [True, True]
+
+
+def test_inputs_that_do_not_satisfy_the_statement_fail_in_prove():
+    """storage_proof_tests.rs:29-41 at the prover level: commit() accepts, prove() fails (upstream panics inside prove with
+    'set twice with different values')."""
+    bad = th.circuit_test_inputs(); bad.public.root_hash = pkg.BytesDigest(bytes(32))
+    prover = pkg.WormholeProver.new(pkg.CircuitConfig.standard_recursion_config()).commit(bad)
+    with pytest.raises(RuntimeError, match="Failed to prove: .*set twice with different values"):
+        prover.prove()
+
+
+def test_circuit_binaries_round_trip_for_the_built_circuit(tmp_path):
+    """circuit_data_tests.rs:96-183: write common.bin / verifier.bin / the prover artefact, load prover and verifier back from the files,
+    prove the test inputs' witness and verify."""
+    written = pkg.generate_circuit_binaries(str(tmp_path), include_prover=True)          # circuit-builder/src/lib.rs:11-66: non-zk wormhole circuit
+    assert set(written) == {"common.bin", "verifier.bin", "prover.qpkg"}
+    src = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_config())
+    w, p = src.generate_witness(th.circuit_test_inputs())
+    prover = pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin"))
+    proof = prover.commit(pkg.SyntheticInputs(wires=w, public_inputs=p)).prove()
+    pkg.WormholeVerifier.new_from_files(str(tmp_path / "verifier.bin"), str(tmp_path / "common.bin")).verify(proof)
+    assert _expected(pkg.PublicCircuitInputs.try_from_proof(proof))
+    shape = ReferenceCircuitShape(open(tmp_path / "common.bin", "rb").read(), open(tmp_path / "verifier.bin", "rb").read())
+    assert shape.desc.degree_bits == 13 and shape.desc.num_public_inputs == 16
+
+
+def test_aggregator_takes_real_leaves_and_pads_with_the_dummy():
+    """aggregator_tests.rs:60-112: leaf proofs of the reference's inputs, padded with the circuit's dummy proof; the aggregated public
+    inputs parse back into the leaves' PublicCircuitInputs."""
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_config())
+    agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, 2))
+    other = th.circuit_test_inputs(); other.public.exit_account = pkg.BytesDigest(bytes([7] * 32))
+    agg.prove_leaves([th.circuit_test_inputs(), other, th.circuit_test_inputs()], salt_seed=5)
+    res = agg.aggregate()
+    assert res.num_real == 3 and len(res.proofs) == 4
+
+    class Agg:
+        public_inputs = res.public_inputs
+    leaves = pkg.PublicCircuitInputs.try_from_aggregated(Agg, 16, 4)
+    assert _expected(leaves[0]) and leaves[1].exit_account == bytes([7] * 32) and _expected(leaves[3])     # the dummy proves the test inputs
+    v = pkg.WormholeVerifier.new(pkg.CircuitConfig.standard_recursion_config())
+    assert v.verify_batch(res.proofs) == [True] * 4
+
+
+def test_vote_circuit_end_to_end():                               # voting/src/lib.rs:345-361
+    cfg = pkg.CircuitConfig.standard_recursion_config(kind=QPC_VOTE)
+    prover = pkg.WormholeProver.new(cfg)
+    good = th.vote_test_inputs()
+    proof = prover.commit(good).prove()
+    assert proof.public_inputs == good.public_inputs.proposal_id + good.public_inputs.merkle_root + [1] + good.public_inputs.nullifier
+    pkg.WormholeVerifier.new(cfg).verify(proof)
+    assert OracleCircuit(prover.circuit_data.desc).verify(proof.to_bytes()) is None
+    bad = th.vote_test_inputs(); bad.private_inputs.actual_merkle_depth = 1                               # test_invalid_merkle_proof
+    with pytest.raises(RuntimeError, match="Failed to prove"):
+        pkg.WormholeProver.new(cfg).commit(bad).prove()

@@ -15,12 +15,6 @@ def tiny_zk():
     sc = SynthCircuit("TZ"); return sc, OracleCircuit(sc.desc)
 
 
-def check_witness(oc, wires, pis):
-    L = oracle(); L.orc_check_witness.argtypes = [ctypes.c_void_p, u64p, u64p]
-    rc = L.orc_check_witness(oc.h, ptr(wires), ptr(pis))
-    return None if rc == 0 else L.orc_last_error().decode()
-
-
 def test_synthetic_witness_satisfies_gates_and_copy_constraints(tiny, tiny_zk):
     for sc, oc in (tiny, tiny_zk):
         for seed in range(3):

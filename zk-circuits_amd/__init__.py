@@ -10,8 +10,10 @@ import it with importlib.import_module("zk-circuits_amd").
 The product path never touches oracle/ and has no CPU fallback: loading fails loudly if libqpgpu.so is missing.
 """
 from .ffi import lib, QpgpuError, CircuitDesc, ProveOpts, Gate  # noqa: F401
-from .prover import (CircuitConfig, CircuitInputs, ProofWithPublicInputs, WormholeProver,  # noqa: F401
+from .prover import (CircuitConfig, SyntheticInputs, ProofWithPublicInputs, WormholeProver,  # noqa: F401
                      WormholeCircuitData)
+from .inputs import (BytesDigest, CircuitInputs, PublicCircuitInputs, PrivateCircuitInputs, ProcessedStorageProof,  # noqa: F401
+                     VoteCircuitData, VotePublicInputs, VotePrivateInputs, nullifier_from_preimage, unspendable_account_from_secret)
 from .verifier import WormholeVerifier  # noqa: F401
 from .circuit_builder import generate_circuit_binaries  # noqa: F401
 from .aggregator import (WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves, AggregatedProof,  # noqa: F401

@@ -12,7 +12,7 @@ import ctypes
 import os
 import numpy as np
 from . import ffi
-from .prover import ProofWithPublicInputs
+from .prover import ProofWithPublicInputs, SyntheticInputs
 
 DEFAULT_TREE_BRANCHING_FACTOR = 2   # tree.rs:17
 DEFAULT_TREE_DEPTH = 3              # tree.rs:20
@@ -58,7 +58,11 @@ class WormholeProofAggregator:
         Salts: ChaCha8(salt_key, stream i) for leaf i with a fresh OS-RNG key per call, unless `salt_seed` is given (tests: the
         public test key with stream salt_seed + i, reproducible by the oracle)."""
         cd = self.leaf_circuit_data
-        ws, ps = zip(*[cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs) for ci in circuit_inputs_list])
+        def witness(ci):
+            if not isinstance(ci, SyntheticInputs):                       # the reference's CircuitInputs on the built wormhole circuit
+                return cd.generate_witness(ci, os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY)
+            return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
+        ws, ps = zip(*[witness(ci) for ci in circuit_inputs_list])
         b = len(ws)
         wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in ws])
         pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for p in ps])

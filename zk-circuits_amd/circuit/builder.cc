@@ -1,0 +1,168 @@
+// Builder::build (public-input hash, zk blinding rows, padding, sigma, descriptor) and Builder::generate (witness generation).
+#include "builder.h"
+#include <algorithm>
+#include <cstring>
+
+namespace qpc {
+using namespace qp;
+
+namespace {
+// FriReductionStrategy::ConstantArityBits(4, 5) under rate_bits 3 / cap_height 4 (the strategy both reference configs write,
+// csrc/artifacts.hip fri_config): fold by 16 while the degree is above 2^5 and the folded layer still has at least a cap's worth of leaves.
+// Pinned by the reference's artefacts: k = 13 -> [4,4] (aggregator/data/dummy_proof.bin), k = 14 -> [4,4,4] (bench-data/common.bin).
+std::vector<uint32_t> fri_arities(uint32_t degree_bits) {
+  std::vector<uint32_t> a; uint32_t d = degree_bits;
+  while (d > 5 && d + 3 >= 4 + 4) { a.push_back(4); d -= 4; }
+  return a;
+}
+uint32_t ceil_log2(size_t x) { uint32_t k = 0; while ((size_t(1) << k) < x) k++; return k; }
+const int DEGREE[K_KINDS] = {0, 1, 1, 2, 3, 7};            // constraint degree per row kind: orders the gate list and forms the selector groups
+const uint32_t TAG[K_KINDS] = {QPGPU_GATE_NOOP, QPGPU_GATE_CONSTANT, QPGPU_GATE_PUBLIC_INPUT, QPGPU_GATE_BASESUM2, QPGPU_GATE_ARITHMETIC, QPGPU_GATE_POSEIDON};
+const uint64_t PARAM[K_KINDS] = {0, 2, 0, BASESUM_LIMBS, ARITH_OPS, 0};
+const uint32_t NUM_QUERIES = 28, CAP_HEIGHT = 4, POW_BITS = 16, RATE_BITS = 3;
+}
+
+void Builder::build() {
+  if (built_) return;
+  // public inputs: hashed in-circuit, the digest tied to the PublicInput gate's wires (plonky2 does the same in build()).
+  { Hash4 h = hash_n_to_hash_no_pad(public_inputs_); for (int i = 0; i < 4; i++) connect(h.e[i], wire(0, i)); }
+  gate_rows_ = row_kind_.size();
+  uint32_t k = std::max<uint32_t>(5, ceil_log2(gate_rows_));
+  if (zk_) {
+    // Blinding rows, sized as plonky2's blinding_counts does: every wire polynomial is opened at zeta (D = 2 base elements) and at each FRI
+    // query (one leaf, plus what the folding points and the final polynomial reveal): `regular` rows of random wires hide the wire
+    // polynomials; `z` pairs of rows holding the same random routed values under a copy constraint give Z and the partial products
+    // random factors (2D openings: zeta and g*zeta).
+    for (;; k++) {
+      const auto ar = fri_arities(k);
+      size_t fold = 0, red = 0; for (uint32_t a : ar) { fold += (size_t(1) << a) - 1; red += a; }
+      const size_t final_coeffs = size_t(1) << (k - red), fri_open = NUM_QUERIES * (1 + 2 * fold + 2 * final_coeffs);
+      blind_plain_ = 2 + fri_open; blind_pairs_ = 4 + fri_open;
+      if (gate_rows_ + blind_plain_ + 2 * blind_pairs_ <= (size_t(1) << k)) break;
+    }
+    blind_plain_first_ = gate_rows_; blind_pair_first_ = gate_rows_ + blind_plain_;
+  }
+  n_ = size_t(1) << k;
+  row_kind_.resize(n_, K_NOOP); row_c0_.resize(n_, 0); row_c1_.resize(n_, 0);
+
+  // copy classes
+  cls_.resize(cells_.size());
+  { std::vector<uint32_t> index(cells_.size(), UINT32_MAX); ncls_ = 0;
+    for (size_t t = 0; t < cells_.size(); t++) { uint32_t r = find((uint32_t)t); if (index[r] == UINT32_MAX) index[r] = (uint32_t)ncls_++; cls_[t] = index[r]; } }
+  for (size_t t = 0; t < cells_.size(); t++) if (cells_[t].row >= 0) wire_targets_.push_back((Target)t);
+
+  // sigma: the routed cells of a class form one cycle; a blinding pair swaps its two cells
+  std::vector<uint32_t> sigma((size_t)R * n_);
+  for (size_t i = 0; i < sigma.size(); i++) sigma[i] = (uint32_t)i;
+  { std::vector<std::vector<uint32_t>> members(ncls_);
+    for (Target t : wire_targets_) if (cells_[t].col < R) members[cls_[t]].push_back((uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row));
+    for (auto& m : members) for (size_t i = 0; i + 1 <= m.size() && m.size() > 1; i++) sigma[m[i]] = m[(i + 1) % m.size()]; }
+  for (size_t p = 0; p < blind_pairs_; p++) for (int c = 0; c < R; c++) {
+    const size_t a = (size_t)c * n_ + blind_pair_first_ + 2 * p, b = a + 1; sigma[a] = (uint32_t)b; sigma[b] = (uint32_t)a;
+  }
+
+  // gate list ordered by degree; selector groups as upstream forms them (a group grows while size + next degree < 8): [0,5), [5,6)
+  int gate_index[K_KINDS];
+  { std::vector<int> kinds; for (int i = 0; i < K_KINDS; i++) kinds.push_back(i);
+    std::stable_sort(kinds.begin(), kinds.end(), [](int a, int b) { return DEGREE[a] < DEGREE[b]; });
+    for (size_t i = 0; i < kinds.size(); i++) gate_index[kinds[i]] = (int)i;
+    sel_idx_.assign(kinds.size(), 0); size_t start = 0;
+    while (start < kinds.size()) {
+      size_t size = 0;
+      while (start + size < kinds.size() && (int)size + DEGREE[kinds[start + size]] < 8) size++;
+      for (size_t i = 0; i < size; i++) sel_idx_[start + i] = (uint32_t)(groups_.size() / 2);
+      groups_.push_back((uint32_t)start); groups_.push_back((uint32_t)(start + size)); start += size;
+    }
+    for (int kd : kinds) { qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = TAG[kd]; g.param = PARAM[kd]; gates_.push_back(g); } }
+  const int nsel = (int)(groups_.size() / 2);                  // 2 for this gate set; NC = nsel + 2 local constants
+  k_is_.resize(R); { u64 x = 1; for (int j = 0; j < R; j++) { k_is_[j] = x; x = gl_mul(x, GL_GEN); } }
+  constants_sigmas_.assign((size_t)(nsel + 2 + R) * n_, 0);
+  u64* cs = constants_sigmas_.data();
+  for (size_t i = 0; i < n_; i++) {
+    const int gi = gate_index[row_kind_[i]];
+    for (int sc = 0; sc < nsel; sc++) cs[(size_t)sc * n_ + i] = (int)sel_idx_[gi] == sc ? (u64)gi : 0xFFFFFFFFULL;
+    cs[(size_t)nsel * n_ + i] = row_c0_[i]; cs[(size_t)(nsel + 1) * n_ + i] = row_c1_[i];
+  }
+  { std::vector<u64> wpow(n_); u64 w = gl_root((int)k), x = 1;
+    for (size_t i = 0; i < n_; i++) { wpow[i] = x; x = gl_mul(x, w); }
+    for (int j = 0; j < R; j++) for (size_t i = 0; i < n_; i++) { uint32_t t = sigma[(size_t)j * n_ + i]; cs[(size_t)(nsel + 2 + j) * n_ + i] = gl_mul(k_is_[t / n_], wpow[t % n_]); } }
+
+  qpgpu_circuit_desc& d = desc_; memset(&d, 0, sizeof d);
+  d.degree_bits = k; d.num_wires = W; d.num_routed = R; d.num_constants = (uint32_t)(nsel + 2); d.num_challenges = 2;
+  d.quotient_degree_factor = 8; d.num_partial_products = 9; d.num_public_inputs = (uint32_t)public_inputs_.size(); d.num_gate_constraints = 123;
+  d.zero_knowledge = zk_; d.fri_rate_bits = RATE_BITS; d.fri_cap_height = CAP_HEIGHT; d.fri_num_queries = NUM_QUERIES; d.fri_pow_bits = POW_BITS;
+  { const auto ar = fri_arities(k); d.fri_num_layers = (uint32_t)ar.size(); for (size_t i = 0; i < ar.size(); i++) d.fri_arity_bits[i] = ar[i]; }
+  d.num_gates = (uint32_t)gates_.size(); d.num_selector_groups = (uint32_t)nsel; d.gates = gates_.data(); d.selector_indices = sel_idx_.data();
+  d.selector_group_ranges = groups_.data(); d.k_is = k_is_.data(); d.constants_sigmas = cs;
+  // Circuit digest: binds every constants/sigmas value and the shape (upstream hashes the constants/sigmas cap with the common data;
+  // any four felts that commit to the circuit serve the transcript — this one is this builder's own).
+  { u64 acc[4] = {k, (u64)zk_, (u64)public_inputs_.size(), (u64)gate_rows_};
+    std::vector<u64> buf(4 + n_);
+    for (int col = 0; col < nsel + 2 + R; col++) {
+      memcpy(buf.data(), acc, sizeof acc); memcpy(buf.data() + 4, cs + (size_t)col * n_, n_ * sizeof(u64));
+      hash_no_pad(buf.data(), buf.size(), acc);
+    }
+    memcpy(d.circuit_digest, acc, sizeof acc); }
+  built_ = true;
+}
+
+std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const {
+  const size_t n = n_;
+  std::vector<u64> val(ncls_, 0); std::vector<uint8_t> have(ncls_, 0);
+  std::string err;
+  auto name = [&](Target t) { const Cell& c = cells_[t]; return c.row < 0 ? "virtual target " + std::to_string(t) : "wire (row " + std::to_string(c.row) + ", column " + std::to_string(c.col) + ")"; };
+  auto set = [&](Target t, u64 v) {
+    const uint32_t c = cls_[t];
+    if (have[c] && val[c] != v) { if (err.empty()) err = "copy-constrained targets set twice with different values: " + name(t) + " was " + std::to_string(val[c]) + ", now " + std::to_string(v); return false; }
+    val[c] = v; have[c] = 1; return true;
+  };
+  auto get = [&](Target t) -> u64 {
+    const uint32_t c = cls_[t];
+    if (!have[c] && err.empty()) err = name(t) + " is read before any generator has set it";
+    return val[c];
+  };
+  for (size_t i = 0; i < inputs_.size(); i++) {
+    if (inputs[i] >= P) return "input target " + std::to_string(i) + " is not a canonical field element";
+    if (!set(inputs_[i], inputs[i])) return err;
+  }
+  for (const Op& op : ops_) {
+    switch (op.kind) {
+      case OP_CONST: set(op.out, op.k0); break;
+      case OP_ARITH: { const u64 a = get(op.a), b = get(op.b), c = get(op.c); set(op.out, gl_add(gl_mul(op.k0, gl_mul(a, b)), gl_mul(op.k1, c))); break; }
+      case OP_INV: { const u64 a = get(op.a); set(op.out, a ? gl_inv(a) : 0); break; }
+      case OP_SPLIT: {
+        const u64 x = get(op.out);
+        if (x >> BASESUM_LIMBS) { if (err.empty()) err = "range check: " + std::to_string(x) + " does not fit " + std::to_string(BASESUM_LIMBS) + " binary limbs"; break; }
+        for (int l = 0; l < BASESUM_LIMBS; l++) set(op.out + 1 + l, (x >> l) & 1);
+        break;
+      }
+      case OP_POSEIDON: {                                           // targets of the row: inputs out..out+11, swap out+12, outputs out+13..out+24
+        u64 st[12]; for (int i = 0; i < 12; i++) st[i] = get(op.out + i);
+        poseidon_permute(st);
+        for (int i = 0; i < 12; i++) set(op.out + 13 + i, st[i]);
+        break;
+      }
+    }
+    if (!err.empty()) return err;
+  }
+  for (size_t i = 0; i < public_inputs_.size(); i++) public_inputs[i] = get(public_inputs_[i]);
+  if (!err.empty()) return err;
+
+  memset(wires, 0, sizeof(u64) * (size_t)W * n);
+  for (Target t : wire_targets_) if (have[cls_[t]]) wires[(size_t)cells_[t].col * n + cells_[t].row] = val[cls_[t]];
+  for (size_t row = 0; row < gate_rows_; row++) if (row_kind_[row] == K_POSEIDON) {
+    u64 in[12]; for (int i = 0; i < 12; i++) in[i] = wires[(size_t)i * n + row];
+    poseidon_gate_row(wires, n, row, in, 0);
+  }
+  if (zk_) {
+    if (!blinding_key) return "a zero-knowledge circuit needs a blinding key";
+    const SaltKey key = salt_key_from_bytes(blinding_key);
+    u64 blk[8]; u64 nblk = 0; int pos = 8;
+    auto rnd = [&]() { if (pos == 8) { salt_block(key, 0x626c696e64ULL /* "blind" */, nblk++, blk); pos = 0; } return blk[pos++]; };
+    for (size_t r = 0; r < blind_plain_; r++) for (int c = 0; c < W; c++) wires[(size_t)c * n + blind_plain_first_ + r] = rnd();
+    for (size_t p = 0; p < blind_pairs_; p++) for (int c = 0; c < R; c++) { const u64 v = rnd(); wires[(size_t)c * n + blind_pair_first_ + 2 * p] = v; wires[(size_t)c * n + blind_pair_first_ + 2 * p + 1] = v; }
+  }
+  return "";
+}
+
+} // namespace qpc

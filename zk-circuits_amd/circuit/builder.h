@@ -1,0 +1,242 @@
+// Circuit builder + witness generator for the leaf gate set (Noop, Constant{2}, PublicInput, BaseSum<2>{63}, Arithmetic{20}, Poseidon)
+// under standard_recursion(_zk)_config: 135 wires, 80 routed, 2 constants per gate. Host-only C++.
+//
+// This is this repo's own builder: it offers the operations the reference's circuit definitions call on plonky2's CircuitBuilder
+// (wormhole/circuit/src/{nullifier,unspendable_account,storage_proof/mod,substrate_account}.rs, common/src/gadgets.rs, voting/src/lib.rs)
+// with the same meaning, and it places gates by its own rules. A circuit built here enforces the same statement as the reference's, with
+// the same public inputs in the same order, but its rows / copy constraints / digest are NOT upstream's (qp-plonky2's builder is not on
+// disk; gate placement is "parity unpinned"): proofs are checked by this repo's verifier data, not by the reference's verifier.bin.
+//
+// Model: a Target is a wire cell (row, column) or a virtual slot; connect() merges targets into copy classes (union-find). Every gate
+// operand is a wire cell merged with the target it carries. Witness generation replays the operation list in build order over class
+// values; writing a class twice with different values is the failure the reference's tests expect from bad inputs
+// ("... set twice with different values", wormhole/tests/src/circuit/storage_proof_tests.rs:31).
+#pragma once
+#include "../../include/qpgpu.h"
+#include "../csrc/poseidon.h"
+#include "../csrc/salt.h"
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+namespace qpc {
+using qp::u64;
+typedef uint32_t Target;
+
+enum RowKind : uint8_t { K_NOOP = 0, K_CONST = 1, K_PI = 2, K_BASESUM = 3, K_ARITH = 4, K_POSEIDON = 5, K_KINDS = 6 };
+static const int W = 135, R = 80, BASESUM_LIMBS = 63, ARITH_OPS = 20, NSEL = 2, NC = 4;
+static const u64 P = qp::GL_P;
+
+struct Hash4 { Target e[4]; };
+struct BoolT { Target t; };
+
+// One Poseidon gate row's wires from its 12 inputs (wire layout of plonky2's PoseidonGate: inputs 0..11, outputs 12..23, swap 24, delta 25..28,
+// first full rounds 29..64 (rounds 1-3), partial 65..86, second full rounds 87..134).
+inline void poseidon_gate_row(u64* wires, size_t n, size_t row, const u64 in[12], u64 swap) {
+  using namespace qp;
+  auto Wr = [&](int col) -> u64& { return wires[(size_t)col * n + row]; };
+  const u64* rc = POSEIDON_RC_HOST;
+  u64 st[12];
+  for (int i = 0; i < 12; i++) Wr(i) = in[i];
+  Wr(24) = swap;
+  for (int i = 0; i < 4; i++) {
+    u64 delta = swap ? gl_sub(in[i + 4], in[i]) : 0; Wr(25 + i) = delta;
+    st[i] = gl_add(in[i], delta); st[i + 4] = gl_sub(in[i + 4], delta);
+  }
+  for (int i = 8; i < 12; i++) st[i] = in[i];
+  int round = 0;
+  for (int r = 0; r < 4; r++, round++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+    if (r) for (int i = 0; i < 12; i++) Wr(29 + 12 * (r - 1) + i) = st[i];
+    for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
+    mds_layer(st);
+  }
+  for (int r = 0; r < 22; r++, round++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+    Wr(65 + r) = st[0]; st[0] = sbox7(st[0]);
+    mds_layer(st);
+  }
+  for (int r = 0; r < 4; r++, round++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * round + i]);
+    for (int i = 0; i < 12; i++) Wr(87 + 12 * r + i) = st[i];
+    for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
+    mds_layer(st);
+  }
+  for (int i = 0; i < 12; i++) Wr(12 + i) = st[i];
+}
+
+class Builder {
+ public:
+  explicit Builder(bool zero_knowledge) : zk_(zero_knowledge) {
+    add_row(K_PI, 0, 0);                                   // row 0: the PublicInput gate (wires 0..3 = hash of the public inputs)
+    zero_ = constant(0); one_ = constant(1);
+  }
+
+  // ---- targets
+  Target add_virtual() { return new_target(-1, 0); }
+  Target add_input() { Target t = add_virtual(); inputs_.push_back(t); return t; }          // a PartialWitness slot, in allocation order
+  std::vector<Target> add_inputs(int k) { std::vector<Target> v; for (int i = 0; i < k; i++) v.push_back(add_input()); return v; }
+  Hash4 add_input_hash() { Hash4 h; for (auto& e : h.e) e = add_input(); return h; }
+  void register_public_input(Target t) { public_inputs_.push_back(t); }
+  Target add_public_input() { Target t = add_input(); register_public_input(t); return t; }
+  Hash4 add_public_input_hash() { Hash4 h; for (auto& e : h.e) e = add_public_input(); return h; }
+
+  Target constant(u64 c) {
+    c %= P;
+    auto it = consts_.find(c); if (it != consts_.end()) return it->second;
+    if (const_slot_ == 0) const_row_ = add_row(K_CONST, 0, 0);
+    Target t = wire(const_row_, const_slot_);
+    (const_slot_ == 0 ? row_c0_ : row_c1_)[const_row_] = c;
+    const_slot_ ^= 1;
+    consts_[c] = t; const_val_[t] = c;
+    ops_.push_back(Op{OP_CONST, t, 0, 0, 0, c, 0, 0});
+    return t;
+  }
+  Target zero() const { return zero_; }
+  Target one() const { return one_; }
+  BoolT constant_bool(bool b) { return BoolT{b ? one_ : zero_}; }
+
+  void connect(Target a, Target b) { unite(a, b); }
+  void connect_hashes(const Hash4& a, const Hash4& b) { for (int i = 0; i < 4; i++) connect(a.e[i], b.e[i]); }
+  void assert_zero(Target t) { connect(t, zero_); }
+
+  // ---- arithmetic: out = k0 * a * b + k1 * c on an Arithmetic gate slot (20 per row; a row's slots share (k0, k1))
+  Target arithmetic(u64 k0, u64 k1, Target a, Target b, Target c) {
+    using namespace qp;
+    u64 va = 0, vb = 0, vc = 0;
+    const bool ca = is_const(a, va), cb = is_const(b, vb), cc = is_const(c, vc);
+    if (ca && cb && cc) return constant(gl_add(gl_mul(k0, gl_mul(va, vb)), gl_mul(k1, vc)));
+    if (k0 == 0 || (ca && va == 0) || (cb && vb == 0)) {     // no product term
+      if (cc) return constant(gl_mul(k1, vc));
+      if (k1 == 1) return c;
+    }
+    if ((k1 == 0 || (cc && vc == 0)) && k0 == 1) {           // no addend, multiplication by one
+      if (ca && va == 1) return b;
+      if (cb && vb == 1) return a;
+    }
+    if (find(a) > find(b)) std::swap(a, b);                 // the product commutes: one cache entry per unordered pair
+    auto key = std::make_tuple(k0, k1, find(a), find(b), find(c));
+    auto hit = arith_cache_.find(key); if (hit != arith_cache_.end()) return hit->second;
+    auto& open = open_arith_[std::make_pair(k0, k1)];
+    if (open.second == 0) { open.first = add_row(K_ARITH, k0, k1); }
+    const uint32_t row = open.first; const int s = open.second;
+    open.second = (s + 1) % ARITH_OPS;
+    unite(wire(row, 4 * s), a); unite(wire(row, 4 * s + 1), b); unite(wire(row, 4 * s + 2), c);
+    Target out = wire(row, 4 * s + 3);
+    ops_.push_back(Op{OP_ARITH, out, wire(row, 4 * s), wire(row, 4 * s + 1), wire(row, 4 * s + 2), k0, k1, 0});
+    arith_cache_[key] = out;
+    return out;
+  }
+  Target add(Target a, Target b) { return arithmetic(1, 1, a, one_, b); }
+  Target sub(Target a, Target b) { return arithmetic(1, P - 1, a, one_, b); }
+  Target mul(Target a, Target b) { return arithmetic(1, 0, a, b, zero_); }
+  Target mul_const(u64 k, Target a) { return arithmetic(k % P, 0, a, one_, zero_); }
+  Target mul_add(Target a, Target b, Target c) { return arithmetic(1, 1, a, b, c); }
+  BoolT not_(BoolT b) { return BoolT{sub(one_, b.t)}; }
+  BoolT and_(BoolT a, BoolT b) { return BoolT{mul(a.t, b.t)}; }
+  BoolT or_(BoolT a, BoolT b) { return BoolT{arithmetic(P - 1, 1, a.t, b.t, add(a.t, b.t))}; }       // a + b - ab
+  Target select(BoolT b, Target x, Target y) { return mul_add(b.t, sub(x, y), y); }                  // b ? x : y
+
+  // x == y as a boolean. One hint (the inverse of the difference); constraints: diff * inv = 1 - eq, diff * eq = 0.
+  BoolT is_equal(Target x, Target y) {
+    Target diff = sub(x, y);
+    u64 vd;
+    if (is_const(diff, vd)) return constant_bool(vd == 0);
+    Target inv = add_virtual();
+    ops_.push_back(Op{OP_INV, inv, diff, 0, 0, 0, 0, 0});
+    Target ne = mul(diff, inv);
+    Target eq = sub(one_, ne);
+    assert_zero(mul(diff, eq));
+    return BoolT{eq};
+  }
+
+  // Little-endian bits of x, which must be < 2^nbits: one BaseSum<2> row (wire 0 = sum, wires 1..63 = limbs, each constrained to {0,1});
+  // limbs from nbits up are tied to zero.
+  std::vector<BoolT> split_le(Target x, int nbits) {
+    const uint32_t row = add_row(K_BASESUM, 0, 0);
+    unite(wire(row, 0), x);
+    ops_.push_back(Op{OP_SPLIT, wire(row, 0), 0, 0, 0, 0, 0, row});
+    std::vector<BoolT> bits;
+    for (int l = 0; l < BASESUM_LIMBS; l++) { Target t = wire(row, 1 + l); if (l < nbits) bits.push_back(BoolT{t}); else assert_zero(t); }
+    return bits;
+  }
+  void range_check(Target x, int nbits) { split_le(x, nbits); }
+
+  // Poseidon permutation on a gate row (swap = 0) and the no-padding sponge (rate 8, overwrite mode) over it.
+  void permute(Target st[12]) {
+    const uint32_t row = add_row(K_POSEIDON, 0, 0);
+    const Target first = wire(row, 0);                      // targets of a fresh row are numbered in creation order: inputs first .. first+11,
+    for (int i = 0; i < 12; i++) unite(wire(row, i), st[i]);
+    unite(wire(row, 24), zero_);                            // swap first+12,
+    ops_.push_back(Op{OP_POSEIDON, first, 0, 0, 0, 0, 0, row});
+    for (int i = 0; i < 12; i++) st[i] = wire(row, 12 + i); // outputs first+13 .. first+24
+  }
+  Hash4 hash_n_to_hash_no_pad(const std::vector<Target>& in) {
+    Target st[12]; for (auto& s : st) s = zero_;
+    for (size_t off = 0; off < in.size(); off += 8) {
+      for (size_t i = 0; i < 8 && off + i < in.size(); i++) st[i] = in[off + i];
+      permute(st);
+    }
+    Hash4 h; for (int i = 0; i < 4; i++) h.e[i] = st[i];
+    return h;
+  }
+
+  // ---- finish: public-input hash, zk blinding rows, padding, sigma, descriptor. After this the builder is a circuit.
+  void build();
+
+  // ---- the circuit
+  size_t degree() const { return n_; }
+  size_t num_inputs() const { return inputs_.size(); }
+  size_t num_gate_rows() const { return gate_rows_; }
+  const qpgpu_circuit_desc& desc() const { return desc_; }
+  void row_counts(uint32_t out[K_KINDS]) const { for (int k = 0; k < K_KINDS; k++) out[k] = 0; for (size_t r = 0; r < gate_rows_; r++) out[row_kind_[r]]++; }
+  // generate_partial_witness: inputs[num_inputs()] in allocation order -> wires [135][n] column-major, public_inputs[]. `blinding_key`
+  // (32 bytes) seeds the zk blinding rows. Returns "" or the failure.
+  std::string generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const;
+
+ private:
+  enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON };
+  struct Op { uint8_t kind; Target out, a, b, c; u64 k0, k1; uint32_t row; };
+  struct Cell { int32_t row; int16_t col; };
+
+  Target new_target(int32_t row, int16_t col) { cells_.push_back(Cell{row, col}); parent_.push_back((uint32_t)parent_.size()); return (Target)(cells_.size() - 1); }
+  Target wire(uint32_t row, int col) {
+    auto key = ((u64)row << 8) | (u64)col;
+    auto it = wire_ids_.find(key); if (it != wire_ids_.end()) return it->second;
+    Target t = new_target((int32_t)row, (int16_t)col); wire_ids_[key] = t; return t;
+  }
+  uint32_t add_row(uint8_t kind, u64 c0, u64 c1) { row_kind_.push_back(kind); row_c0_.push_back(c0); row_c1_.push_back(c1); return (uint32_t)row_kind_.size() - 1; }
+  uint32_t find(uint32_t x) { while (parent_[x] != x) { parent_[x] = parent_[parent_[x]]; x = parent_[x]; } return x; }
+  void unite(Target a, Target b) {
+    uint32_t ra = find(a), rb = find(b); if (ra == rb) return;
+    // a class keeps its constant, if any (constant folding looks it up through the representative)
+    auto ca = const_val_.find(ra), cb = const_val_.find(rb);
+    if (ra > rb) std::swap(ra, rb);
+    parent_[rb] = ra;
+    if (ca != const_val_.end()) const_val_[ra] = ca->second; else if (cb != const_val_.end()) const_val_[ra] = cb->second;
+  }
+  bool is_const(Target t, u64& v) { auto it = const_val_.find(find(t)); if (it == const_val_.end()) return false; v = it->second; return true; }
+
+  bool zk_; bool built_ = false;
+  std::vector<Cell> cells_; std::vector<uint32_t> parent_;
+  std::unordered_map<u64, Target> wire_ids_;
+  std::vector<uint8_t> row_kind_; std::vector<u64> row_c0_, row_c1_;
+  std::vector<Op> ops_;
+  std::vector<Target> inputs_, public_inputs_;
+  std::map<u64, Target> consts_; std::map<uint32_t, u64> const_val_;
+  uint32_t const_row_ = 0; int const_slot_ = 0;
+  std::map<std::pair<u64, u64>, std::pair<uint32_t, int>> open_arith_;
+  std::map<std::tuple<u64, u64, uint32_t, uint32_t, uint32_t>, Target> arith_cache_;
+  Target zero_, one_;
+  // after build()
+  size_t n_ = 0, gate_rows_ = 0, blind_plain_first_ = 0, blind_plain_ = 0, blind_pair_first_ = 0, blind_pairs_ = 0;
+  std::vector<uint32_t> cls_; size_t ncls_ = 0;
+  std::vector<Target> wire_targets_;
+  std::vector<u64> constants_sigmas_, k_is_;
+  std::vector<qpgpu_gate> gates_; std::vector<uint32_t> sel_idx_, groups_;
+  qpgpu_circuit_desc desc_{};
+};
+
+} // namespace qpc

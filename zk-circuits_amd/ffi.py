@@ -168,6 +168,124 @@ def synth_lib():
     return _synth
 
 
+class WormholeInputsC(ctypes.Structure):
+    """qpw_circuit_inputs (include/qpcircuit.h)."""
+    _fields_ = [("funding_amount_le", ctypes.c_uint8 * 16), ("nullifier", ctypes.c_uint8 * 32), ("root_hash", ctypes.c_uint8 * 32),
+                ("exit_account", ctypes.c_uint8 * 32), ("secret", ctypes.c_uint8 * 32), ("transfer_count", ctypes.c_uint64),
+                ("funding_account", ctypes.c_uint8 * 32), ("unspendable_account", ctypes.c_uint8 * 32),
+                ("proof_len", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("proof_nodes", ctypes.POINTER(ctypes.c_char_p)), ("proof_node_lens", ctypes.POINTER(ctypes.c_uint32)),
+                ("proof_indices", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class WormholePublicInputsC(ctypes.Structure):
+    _fields_ = [("funding_amount_le", ctypes.c_uint8 * 16), ("nullifier", ctypes.c_uint8 * 32), ("root_hash", ctypes.c_uint8 * 32),
+                ("exit_account", ctypes.c_uint8 * 32)]
+
+
+class VoteInputsC(ctypes.Structure):
+    """qpv_vote_inputs (include/qpcircuit.h)."""
+    _fields_ = [("proposal_id", ctypes.c_uint64 * 4), ("merkle_root", ctypes.c_uint64 * 4), ("vote", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("nullifier", ctypes.c_uint64 * 4), ("private_key", ctypes.c_uint64 * 4), ("merkle_siblings", u64p),
+                ("path_indices", ctypes.POINTER(ctypes.c_uint8)), ("num_siblings", ctypes.c_uint32), ("num_path_indices", ctypes.c_uint32),
+                ("actual_merkle_depth", ctypes.c_uint32), ("reserved2", ctypes.c_uint32)]
+
+
+QPGPU_ERR_WITNESS = -8
+QPC_WORMHOLE, QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_VOTE = range(6)
+_circuit = None
+
+
+def circuit_lib():
+    """libqpcircuit.so — host-only: the reference's circuits + witness generation (include/qpcircuit.h)."""
+    global _circuit
+    if _circuit is None:
+        so = os.path.join(_HERE, "libqpcircuit.so")
+        if not os.path.exists(so):
+            raise ImportError("zk-circuits_amd: %s not built — run __graft_entry__.build()" % so)
+        L = ctypes.CDLL(so)
+        L.qpc_last_error.restype = ctypes.c_char_p
+        L.qpc_circuit_build.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpc_circuit_destroy.argtypes = [ctypes.c_void_p]
+        L.qpc_circuit_destroy.restype = None
+        L.qpc_circuit_desc.restype = ctypes.POINTER(CircuitDesc)
+        L.qpc_circuit_desc.argtypes = [ctypes.c_void_p]
+        L.qpc_circuit_num_inputs.restype = ctypes.c_size_t
+        L.qpc_circuit_num_inputs.argtypes = [ctypes.c_void_p]
+        L.qpc_circuit_row_counts.restype = None
+        L.qpc_circuit_row_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        L.qpc_generate_witness.argtypes = [ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.c_char_p, u64p, u64p]
+        L.qpw_fill_targets.argtypes = [ctypes.c_uint32, ctypes.POINTER(WormholeInputsC), u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpw_nullifier_from_preimage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_char_p]
+        L.qpw_unspendable_account_from_secret.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        L.qpw_public_inputs_from_felts.argtypes = [u64p, ctypes.c_size_t, ctypes.POINTER(WormholePublicInputsC)]
+        L.qpv_fill_targets.argtypes = [ctypes.POINTER(VoteInputsC), u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpc_hash_no_pad.restype = None
+        L.qpc_hash_no_pad.argtypes = [u64p, ctypes.c_size_t, u64p]
+        _circuit = L
+    return _circuit
+
+
+class CircuitError(ValueError):
+    """A qpcircuit call failed; `code` is the QPGPU_ERR_* status (QPGPU_ERR_WITNESS = -8: the inputs do not satisfy the circuit)."""
+
+    def __init__(self, code, msg):
+        ValueError.__init__(self, msg)
+        self.code = code
+
+
+def circuit_check(rc):
+    if rc != 0:
+        raise CircuitError(rc, circuit_lib().qpc_last_error().decode())
+
+
+def hash_no_pad(felts):
+    a = np.ascontiguousarray(felts, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    circuit_lib().qpc_hash_no_pad(ptr(a), len(a), ptr(out))
+    return out
+
+
+class BuiltCircuit:
+    """One of the reference's circuits built by libqpcircuit (kind = QPC_*): descriptor for qpgpu_circuit_create + witness generation."""
+    ROW_KINDS = ("noop", "constant", "public_input", "base_sum", "arithmetic", "poseidon", "rows_in_use")
+
+    def __init__(self, kind, zero_knowledge=False):
+        h = ctypes.c_void_p()
+        circuit_check(circuit_lib().qpc_circuit_build(kind, 1 if zero_knowledge else 0, ctypes.byref(h)))
+        self.handle, self.kind = h, kind
+        self.desc = circuit_lib().qpc_circuit_desc(h).contents
+        self.n = 1 << self.desc.degree_bits
+        self.N = self.n << self.desc.fri_rate_bits
+        self.W = self.desc.num_wires
+        self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
+
+    def row_counts(self):
+        out = (ctypes.c_uint32 * 7)()
+        circuit_lib().qpc_circuit_row_counts(self.handle, out)
+        return dict(zip(self.ROW_KINDS, list(out)))
+
+    def witness(self, inputs, blinding_key=None):
+        """generate_partial_witness: input-target values -> (wires [W][n], public_inputs). Raises CircuitError (code QPGPU_ERR_WITNESS) when the
+        inputs do not satisfy the circuit."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        wires = np.zeros((self.W, self.n), dtype=np.uint64)
+        pis = np.zeros(self.desc.num_public_inputs, dtype=np.uint64)
+        circuit_check(circuit_lib().qpc_generate_witness(self.handle, ptr(inputs), len(inputs), None if blinding_key is None else bytes(blinding_key),
+                                                         ptr(wires), ptr(pis)))
+        return wires, pis
+
+    def constants_sigmas(self):
+        d = self.desc
+        return np.ctypeslib.as_array(d.constants_sigmas, shape=(d.num_constants + d.num_routed, self.n))
+
+    def __del__(self):
+        try:
+            circuit_lib().qpc_circuit_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def check(rc):
     if rc != 0:
         raise QpgpuError(rc, lib().qpgpu_last_error().decode())

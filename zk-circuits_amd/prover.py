@@ -1,9 +1,13 @@
 """WormholeProver mirror (reference: /root/reference/wormhole/prover/src/lib.rs:74-237).
 
-Same shape as the reference wrapper: `WormholeProver.new(config)` builds the circuit (here: the synthetic
-wormhole-shaped circuit package, because plonky2's CircuitBuilder needs the absent Rust toolchain — SURVEY.md §8(d)) and
-uploads it to the GPU once; `commit(inputs)` fills the witness and may be called only once; `prove()` returns a
-`ProofWithPublicInputs` whose bytes are plonky2's `to_bytes()` layout.
+Same shape as the reference wrapper: `WormholeProver.new(config)` builds the circuit and uploads it to the GPU once;
+`commit(inputs)` fills the witness and may be called only once; `prove()` returns a `ProofWithPublicInputs` whose bytes are plonky2's
+`to_bytes()` layout. Two circuit sources:
+  * the wormhole circuit itself (`CircuitConfig.standard_recursion_config()` / `_zk_config()`): built by libqpcircuit from the reference's
+    circuit definition, committed with the reference's `CircuitInputs` (inputs.py) — same statement and public inputs, this repo's own gate
+    placement (include/qpcircuit.h);
+  * synthetic wormhole-/voting-shaped circuits (`CircuitConfig.synthetic(preset)`, libqpsynth): the shapes pinned by the reference's
+    common.bin, committed with a `SyntheticInputs` seed or an explicit witness — the bench workloads.
 """
 import ctypes
 import os
@@ -14,28 +18,39 @@ P = 0xFFFFFFFF00000001
 
 
 class CircuitConfig:
-    """The two presets the reference uses (wormhole/tests/src/prover/prover_tests.rs:11, wormhole/prover/benches/prover.rs:12)."""
+    """The two configs the reference uses (wormhole/tests/src/prover/prover_tests.rs:11, wormhole/prover/benches/prover.rs:12) for the
+    wormhole circuit (`preset` None, `kind` = which circuit libqpcircuit builds), or a synthetic shape of libqpsynth (`preset` set)."""
 
-    def __init__(self, zero_knowledge, preset):
+    def __init__(self, zero_knowledge, preset=None, kind=ffi.QPC_WORMHOLE):
         self.zero_knowledge = zero_knowledge
         self.preset = preset
+        self.kind = kind
 
     @staticmethod
-    def standard_recursion_config():
-        return CircuitConfig(False, "A")
+    def standard_recursion_config(kind=ffi.QPC_WORMHOLE):
+        return CircuitConfig(False, None, kind)
 
     @staticmethod
-    def standard_recursion_zk_config():
-        return CircuitConfig(True, "B")
+    def standard_recursion_zk_config(kind=ffi.QPC_WORMHOLE):
+        return CircuitConfig(True, None, kind)
+
+    @staticmethod
+    def synthetic(preset):
+        """A/B: wormhole-shaped leaf circuits (k = 13 non-zk / k = 14 zk, the shape of the reference's common.bin), V: voting-shaped 2^20,
+        T/TZ: tiny, R/RT/RT2: recursion-shaped."""
+        return CircuitConfig(preset in ("B", "TZ"), preset)
 
     @staticmethod
     def test_config(zero_knowledge=False):
         return CircuitConfig(zero_knowledge, "TZ" if zero_knowledge else "T")
 
+    def key(self):
+        return (self.preset, self.kind, self.zero_knowledge)
 
-class CircuitInputs:
-    """Stand-in for wormhole_circuit::inputs::CircuitInputs (wormhole/circuit/src/inputs.rs:23-55): a witness seed for
-    the synthetic generator, or an explicit full witness (wires [W][n], public_inputs [16])."""
+
+class SyntheticInputs:
+    """Inputs of a synthetic circuit: a witness seed for the generator, or an explicit full witness (wires [W][n], public_inputs)
+    for any circuit (e.g. one loaded from a package)."""
 
     def __init__(self, seed=None, wires=None, public_inputs=None, salt_key=None):
         if (seed is None) == (wires is None):
@@ -44,7 +59,7 @@ class CircuitInputs:
 
     @staticmethod
     def test_inputs(index=0):
-        return CircuitInputs(seed=0x51570000 + index)
+        return SyntheticInputs(seed=0x51570000 + index)
 
 
 class ProofWithPublicInputs:
@@ -61,20 +76,25 @@ class ProofWithPublicInputs:
 
 
 class WormholeCircuitData:
-    """Resident circuit: synthetic package + qpgpu_circuit handle; shared by provers of the same config."""
+    """Resident circuit: built (libqpcircuit) or synthetic (libqpsynth) circuit + qpgpu_circuit handle; shared by provers of the same config."""
     _cache = {}
 
     def __init__(self, config, device=0):
-        S = ffi.synth_lib()
         L = ffi.lib()
         self.config = config
-        params = ffi.SynthParams()
-        if S.qpsynth_preset(config.preset.encode(), ctypes.byref(params)) != 0:
-            raise ValueError(S.qpsynth_last_error().decode())
-        self._synth = ctypes.c_void_p()
-        if S.qpsynth_circuit_create(ctypes.byref(params), ctypes.byref(self._synth)) != 0:
-            raise ValueError(S.qpsynth_last_error().decode())
-        self.desc = S.qpsynth_circuit_desc(self._synth).contents
+        self._synth = self._built = None
+        if config.preset is None:
+            self._built = ffi.BuiltCircuit(config.kind, config.zero_knowledge)      # WormholeCircuit::new(config).build_prover() (lib.rs:190-202)
+            self.desc = self._built.desc
+        else:
+            S = ffi.synth_lib()
+            params = ffi.SynthParams()
+            if S.qpsynth_preset(config.preset.encode(), ctypes.byref(params)) != 0:
+                raise ValueError(S.qpsynth_last_error().decode())
+            self._synth = ctypes.c_void_p()
+            if S.qpsynth_circuit_create(ctypes.byref(params), ctypes.byref(self._synth)) != 0:
+                raise ValueError(S.qpsynth_last_error().decode())
+            self.desc = S.qpsynth_circuit_desc(self._synth).contents
         self.n = 1 << self.desc.degree_bits
         self.num_wires = self.desc.num_wires
         self.num_public_inputs = self.desc.num_public_inputs
@@ -91,7 +111,7 @@ class WormholeCircuitData:
         self = cls.__new__(cls)
         self.config = None
         self._package = ffi.CircuitPackage(package_bytes)       # owns the arrays desc points into
-        self._synth = None
+        self._synth = self._built = None
         self.desc = self._package.desc
         self.n = 1 << self.desc.degree_bits
         self.num_wires = self.desc.num_wires
@@ -115,14 +135,22 @@ class WormholeCircuitData:
 
     @classmethod
     def get(cls, config, device=0):
-        key = (config.preset, device)
+        key = config.key() + (device,)
         if key not in cls._cache:
             cls._cache[key] = cls(config, device)
         return cls._cache[key]
 
+    def generate_witness(self, circuit_inputs, blinding_key=None):
+        """generate_partial_witness for a built circuit: the reference's CircuitInputs -> (wires, public_inputs)."""
+        if self._built is None:
+            raise RuntimeError("this circuit was not built from the wormhole circuit definition: commit SyntheticInputs")
+        kind = self._built.kind
+        targets = circuit_inputs.fill_targets() if kind == ffi.QPC_VOTE else circuit_inputs.fill_targets(kind)
+        return self._built.witness(targets, blinding_key)
+
     def witness(self, seed):
         if self._synth is None:
-            raise RuntimeError("this circuit was loaded from a package: it has no synthetic witness source, commit an explicit witness")
+            raise RuntimeError("this circuit has no synthetic witness source: commit CircuitInputs (built circuit) or an explicit witness (package)")
         wires = np.zeros((self.num_wires, self.n), dtype=np.uint64)
         pis = np.zeros(self.num_public_inputs, dtype=np.uint64)
         ffi.synth_lib().qpsynth_witness(self._synth, seed, wires.ctypes.data_as(ffi.u64p), pis.ctypes.data_as(ffi.u64p))
@@ -136,7 +164,11 @@ class WormholeCircuitData:
         (wormhole/aggregator/src/util.rs:6-9). The reference's own blobs belong to its real circuit (other digest) and cannot pad a
         synthetic one."""
         if getattr(self, "_dummy", None) is None:
-            wires, pis = self.witness(self.DUMMY_SEED)
+            if self._built is not None:       # the reference's dummy is a proof of CircuitInputs::test_inputs() (prover_tests.rs:56-82)
+                from .test_helpers import circuit_test_inputs
+                wires, pis = self.generate_witness(circuit_test_inputs(), ffi.TEST_SALT_KEY)
+            else:
+                wires, pis = self.witness(self.DUMMY_SEED)
             o = ffi.ProveOpts(); o.salt_stream = self.DUMMY_SEED
             keep = ffi.set_salt_key(o, ffi.TEST_SALT_KEY)      # noqa: F841  (public inputs of the dummy are public anyway)
             buf = ctypes.create_string_buffer(self.proof_size); n = ctypes.c_size_t()
@@ -187,6 +219,17 @@ class WormholeProver:
             raise RuntimeError("prover has already commited to inputs")
         self._targets = False
         cd = self.circuit_data
+        if not isinstance(circuit_inputs, SyntheticInputs):
+            # the reference's inputs on the built circuit; witness generation runs here (upstream defers it into prove(), where a
+            # statement that does not hold fails with "set twice with different values": the error is kept and raised by prove())
+            self._salt_key, self._salt_stream = os.urandom(32), 0
+            try:
+                self._witness = cd.generate_witness(circuit_inputs, os.urandom(32))
+            except ffi.CircuitError as e:
+                if e.code != ffi.QPGPU_ERR_WITNESS:
+                    raise
+                self._witness, self._witness_error = None, str(e)
+            return self
         if circuit_inputs.wires is not None:
             wires = np.ascontiguousarray(circuit_inputs.wires, dtype=np.uint64)
             pis = np.ascontiguousarray(circuit_inputs.public_inputs, dtype=np.uint64)
@@ -203,6 +246,8 @@ class WormholeProver:
 
     def prove(self, pow_witness=None):
         if self._witness is None:
+            if getattr(self, "_witness_error", None):
+                raise RuntimeError("Failed to prove: %s" % self._witness_error)
             raise RuntimeError("Failed to prove: prover has not commited to any inputs")
         cd = self.circuit_data
         wires, pis = self._witness
