@@ -1,41 +1,57 @@
 // End-to-end use of the C++ host mirror (zk-circuits_amd/host/wormhole.hpp) — the analogue of the reference's
-// wormhole/example/src/main.rs:13-74: build the prover, commit inputs, prove, print the proof size and public inputs.
-//   g++ -std=c++17 examples/prove_example.cc -Lzk-circuits_amd -lqpgpu -lqpsynth -Wl,-rpath,$PWD/zk-circuits_amd -o examples/prove_example
+// wormhole/example/src/main.rs:13-74: build the wormhole circuit's prover, commit CircuitInputs::test_inputs(), prove, verify, print the
+// public inputs; then the same call sequence on the synthetic wormhole-shaped circuit (the bench shape).
+//   make -C zk-circuits_amd/csrc ../../examples/prove_example && examples/prove_example [zk]
 #include "../zk-circuits_amd/host/wormhole.hpp"
+#include "test_inputs.hpp"
 #include <chrono>
 #include <cstdio>
+
+static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
 
 int main(int argc, char** argv) {
   using namespace wormhole;
   const bool zk = argc > 1 && std::string(argv[1]) == "zk";
   try {
+    // ---- the wormhole circuit with the reference's inputs
     auto cfg = zk ? CircuitConfig::standard_recursion_zk_config() : CircuitConfig::standard_recursion_config();
     auto t0 = std::chrono::steady_clock::now();
     WormholeProver prover = WormholeProver::create(cfg);                       // WormholeProver::new(config)
     auto t1 = std::chrono::steady_clock::now();
-    CircuitInputs inputs = prover.circuit_data->test_inputs();                 // CircuitInputs::test_inputs()
+    CircuitInputs inputs = test_helpers::circuit_test_inputs();                // CircuitInputs::test_inputs()
     ProofWithPublicInputs proof = prover.commit(inputs).prove();               // prover.commit(&inputs)?.prove()?
     auto t2 = std::chrono::steady_clock::now();
     WormholeProver again(prover.circuit_data);                                 // same resident circuit, second proof
-    ProofWithPublicInputs proof2 = again.commit(prover.circuit_data->test_inputs(1)).prove();
+    CircuitInputs other = inputs; other.pub.exit_account.fill(9);
+    ProofWithPublicInputs proof2 = again.commit(other).prove();
     auto t3 = std::chrono::steady_clock::now();
-    std::printf("circuit build+upload %.1f ms, first prove %.1f ms, second prove %.2f ms\n",
-                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                std::chrono::duration<double, std::milli>(t3 - t2).count());
-    std::printf("proof bytes %zu (second %zu), public inputs:", proof.to_bytes().size(), proof2.to_bytes().size());
-    for (uint64_t x : proof.public_inputs) std::printf(" %016llx", (unsigned long long)x);
-    std::printf("\n");
+    std::printf("wormhole circuit (2^%u rows%s): build+upload %.1f ms, first commit+prove %.1f ms, second %.2f ms, proof %zu bytes\n",
+                prover.circuit_data->common().degree_bits, zk ? ", zk" : "", ms(t0, t1), ms(t1, t2), ms(t2, t3), proof.to_bytes().size());
+    PublicCircuitInputs pub = PublicCircuitInputs::try_from_slice(proof.public_inputs);
+    unsigned long long amount = 0; for (int i = 7; i >= 0; i--) amount = amount << 8 | pub.funding_amount_le[i];
+    std::printf("public inputs: funding_amount %llu, nullifier %02x%02x%02x%02x.., root_hash %02x%02x%02x%02x.., exit_account %02x..\n", amount,
+                pub.nullifier[0], pub.nullifier[1], pub.nullifier[2], pub.nullifier[3], pub.root_hash[0], pub.root_hash[1], pub.root_hash[2], pub.root_hash[3], pub.exit_account[0]);
+    if (amount != 1000000000000ULL || pub.nullifier != inputs.pub.nullifier || pub.root_hash != inputs.pub.root_hash) return 4;   // prover_tests.rs:29-43
     WormholeVerifier verifier(prover.circuit_data);                            // WormholeVerifier::new(config, Some(circuit_data))
     verifier.verify(proof); verifier.verify(proof2);
     ProofWithPublicInputs forged = proof; forged.bytes.back() ^= 1;            // verifier_tests.rs:49-66: a flipped public input must fail
     auto verdicts = verifier.verify_batch({proof, forged, proof2});
     std::printf("verified: %d %d %d\n", (int)verdicts[0], (int)verdicts[1], (int)verdicts[2]);
     if (!verdicts[0] || verdicts[1] || !verdicts[2]) return 3;
+    CircuitInputs bad = inputs; bad.pub.root_hash.fill(0);                     // storage_proof_tests.rs:29-34: commit accepts, prove fails
+    try { WormholeProver(prover.circuit_data).commit(bad).prove(); return 5; } catch (const std::runtime_error& e) { std::printf("invalid root hash rejected: %.96s...\n", e.what()); }
     WormholeProofAggregator agg(TreeAggregationConfig(2, 1));
     agg.push_proof(proof); agg.push_proof(proof2);
     auto leaves = agg.aggregate(proof);
     std::printf("aggregator leaf set: %zu proofs\n", leaves.size());
     try { prover.commit(inputs); return 2; } catch (const std::runtime_error& e) { std::printf("second commit rejected: %s\n", e.what()); }
+    // ---- the synthetic wormhole-shaped circuit (bench shape): seeded full witnesses
+    WormholeProver synth = WormholeProver::create(CircuitConfig::synthetic(zk ? "B" : "A"));
+    auto t4 = std::chrono::steady_clock::now();
+    ProofWithPublicInputs sp = synth.commit(synth.circuit_data->test_inputs()).prove();
+    auto t5 = std::chrono::steady_clock::now();
+    WormholeVerifier(synth.circuit_data).verify(sp);
+    std::printf("synthetic shape %s: commit+prove %.2f ms, verified\n", zk ? "B" : "A", ms(t4, t5));
     return 0;
   } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
 }

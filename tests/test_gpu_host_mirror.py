@@ -120,7 +120,7 @@ def test_cpp_host_mirror_example_runs():
     for mode, size in (("nozk", 132712), ("zk", 148932)):
         r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert "proof bytes %d" % size in r.stdout and "second commit rejected: prover has already commited to inputs" in r.stdout
+        assert "proof %d bytes" % size in r.stdout and "second commit rejected: prover has already commited to inputs" in r.stdout
 
 
 def test_wormhole_verifier_mirror(pkg):
@@ -159,7 +159,10 @@ def test_cpp_host_mirror_example(arg):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "verified: 1 0 1" in r.stdout and "second commit rejected" in r.stdout
     size = 148932 if arg == "zk" else 132712                              # the reference's proof sizes
-    assert "proof bytes %d (second %d)" % (size, size) in r.stdout
+    assert "proof %d bytes" % size in r.stdout and "wormhole circuit (2^%d rows" % (14 if arg == "zk" else 13) in r.stdout
+    assert "funding_amount 1000000000000, nullifier a94c9623" in r.stdout           # prover_tests.rs:29-43: the real circuit on the reference's inputs
+    assert "invalid root hash rejected" in r.stdout and "set twice with different values" in r.stdout
+    assert "synthetic shape %s" % ("B" if arg == "zk" else "A") in r.stdout
 
 
 def test_prove_and_verify_from_files(pkg, tmp_path):

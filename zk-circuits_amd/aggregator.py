@@ -62,7 +62,12 @@ class WormholeProofAggregator:
             if not isinstance(ci, SyntheticInputs):                       # the reference's CircuitInputs on the built wormhole circuit
                 return cd.generate_witness(ci, os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY)
             return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
-        ws, ps = zip(*[witness(ci) for ci in circuit_inputs_list])
+        if len(circuit_inputs_list) > 1 and not isinstance(circuit_inputs_list[0], SyntheticInputs):
+            from concurrent.futures import ThreadPoolExecutor            # witness generation releases the GIL (ctypes): one leaf per host core
+            with ThreadPoolExecutor(max_workers=min(len(circuit_inputs_list), max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
+                ws, ps = zip(*ex.map(witness, circuit_inputs_list))
+        else:
+            ws, ps = zip(*[witness(ci) for ci in circuit_inputs_list])
         b = len(ws)
         wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in ws])
         pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for p in ps])

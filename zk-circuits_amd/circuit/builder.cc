@@ -1,7 +1,11 @@
 // Builder::build (public-input hash, zk blinding rows, padding, sigma, descriptor) and Builder::generate (witness generation).
 #include "builder.h"
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 namespace qpc {
 using namespace qp;
@@ -50,6 +54,10 @@ void Builder::build() {
   { std::vector<uint32_t> index(cells_.size(), UINT32_MAX); ncls_ = 0;
     for (size_t t = 0; t < cells_.size(); t++) { uint32_t r = find((uint32_t)t); if (index[r] == UINT32_MAX) index[r] = (uint32_t)ncls_++; cls_[t] = index[r]; } }
   for (size_t t = 0; t < cells_.size(); t++) if (cells_[t].row >= 0) wire_targets_.push_back((Target)t);
+  // column-major order: witness generation writes the wire matrix column by column
+  std::sort(wire_targets_.begin(), wire_targets_.end(), [&](Target a, Target b) { return cells_[a].col != cells_[b].col ? cells_[a].col < cells_[b].col : cells_[a].row < cells_[b].row; });
+  fill_dst_.reserve(wire_targets_.size()); fill_cls_.reserve(wire_targets_.size());
+  for (Target t : wire_targets_) { fill_dst_.push_back((uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row)); fill_cls_.push_back(cls_[t]); }
 
   // sigma: the routed cells of a class form one cycle; a blinding pair swaps its two cells
   std::vector<uint32_t> sigma((size_t)R * n_);
@@ -106,30 +114,82 @@ void Builder::build() {
   built_ = true;
 }
 
+// Eight ChaCha8 blocks of csrc/salt.h's stream at once (GCC vector extensions; the same keystream as salt_block, block by block).
+typedef uint32_t v8u __attribute__((vector_size(32)));
+#define rotl8(x, r) (((x) << (r)) | ((x) >> (32 - (r))))
+#define QPC_QR(a, b, c, d) do { a += b; d ^= a; d = rotl8(d, 16); c += d; b ^= c; b = rotl8(b, 12); a += b; d ^= a; d = rotl8(d, 8); c += d; b ^= c; b = rotl8(b, 7); } while (0)
+__attribute__((target("avx2"))) static void salt_blocks8_avx2(const SaltKey& key, u64 nonce, u64 block0, u64* out) {
+  v8u s[16], x[16];
+  const uint32_t c[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+  for (int i = 0; i < 4; i++) s[i] = v8u{c[i], c[i], c[i], c[i], c[i], c[i], c[i], c[i]};
+  for (int i = 0; i < 8; i++) s[4 + i] = v8u{key.k[i], key.k[i], key.k[i], key.k[i], key.k[i], key.k[i], key.k[i], key.k[i]};
+  for (int l = 0; l < 8; l++) { const u64 b = block0 + l; s[12][l] = (uint32_t)b; s[13][l] = (uint32_t)(b >> 32); }
+  s[14] = v8u{} + (uint32_t)nonce; s[15] = v8u{} + (uint32_t)(nonce >> 32);
+  for (int i = 0; i < 16; i++) x[i] = s[i];
+  for (int r = 0; r < 4; r++) {
+    QPC_QR(x[0], x[4], x[8], x[12]); QPC_QR(x[1], x[5], x[9], x[13]); QPC_QR(x[2], x[6], x[10], x[14]); QPC_QR(x[3], x[7], x[11], x[15]);
+    QPC_QR(x[0], x[5], x[10], x[15]); QPC_QR(x[1], x[6], x[11], x[12]); QPC_QR(x[2], x[7], x[8], x[13]); QPC_QR(x[3], x[4], x[9], x[14]);
+  }
+  for (int i = 0; i < 16; i++) x[i] += s[i];
+  for (int l = 0; l < 8; l++) for (int i = 0; i < 8; i++) {
+    const u64 z = (u64)x[2 * i][l] | ((u64)x[2 * i + 1][l] << 32);
+    out[8 * l + i] = z >= GL_P ? z - GL_P : z;
+  }
+}
+static void salt_blocks8(const SaltKey& key, u64 nonce, u64 block0, u64* out) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) { salt_blocks8_avx2(key, nonce, block0, out); return; }
+  for (int l = 0; l < 8; l++) salt_block(key, nonce, block0 + l, out + 8 * l);
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const {
-  const size_t n = n_;
-  std::vector<u64> val(ncls_, 0); std::vector<uint8_t> have(ncls_, 0);
+  const size_t n = n_; static const bool tm = getenv("QPC_TIMING") != nullptr; double t0 = now_ms();      // QPC_TIMING (debug): per-phase times on stderr
+  auto lap = [&](const char* what) { if (tm) { double t = now_ms(); fprintf(stderr, "  %-12s %.3f ms\n", what, t - t0); t0 = t; } };
+  const u64 UNSET = ~u64(0);                                          // not a field element: marks a class no generator has written yet
+  std::vector<u64> val(ncls_, UNSET);
   std::string err;
   auto name = [&](Target t) { const Cell& c = cells_[t]; return c.row < 0 ? "virtual target " + std::to_string(t) : "wire (row " + std::to_string(c.row) + ", column " + std::to_string(c.col) + ")"; };
   auto set = [&](Target t, u64 v) {
-    const uint32_t c = cls_[t];
-    if (have[c] && val[c] != v) { if (err.empty()) err = "copy-constrained targets set twice with different values: " + name(t) + " was " + std::to_string(val[c]) + ", now " + std::to_string(v); return false; }
-    val[c] = v; have[c] = 1; return true;
+    u64& slot = val[cls_[t]];
+    if (__builtin_expect(slot != UNSET && slot != v, 0)) { if (err.empty()) err = "copy-constrained targets set twice with different values: " + name(t) + " was " + std::to_string(slot) + ", now " + std::to_string(v); return false; }
+    slot = v; return true;
   };
   auto get = [&](Target t) -> u64 {
-    const uint32_t c = cls_[t];
-    if (!have[c] && err.empty()) err = name(t) + " is read before any generator has set it";
-    return val[c];
+    const u64 v = val[cls_[t]];
+    if (__builtin_expect(v == UNSET, 0)) { if (err.empty()) err = name(t) + " is read before any generator has set it"; return 0; }
+    return v;
   };
+  if (zk_ && !blinding_key) return "a zero-knowledge circuit needs a blinding key";
+  // Zeroing the matrix and writing the zk blinding rows (ChaCha8 keystream) touch no class value: they run beside the operation replay.
+  auto zero_and_blind = [&]() {
+    memset(wires, 0, sizeof(u64) * (size_t)W * n);
+    if (!zk_) return;
+    const SaltKey key = salt_key_from_bytes(blinding_key);
+    u64 blk[64]; u64 nblk = 0; int pos = 64;
+    auto rnd = [&]() { if (pos == 64) { salt_blocks8(key, 0x626c696e64ULL /* "blind" */, nblk, blk); nblk += 8; pos = 0; } return blk[pos++]; };
+    for (int c = 0; c < W; c++) {                                     // column by column: sequential writes
+      u64* col = wires + (size_t)c * n;
+      for (size_t r = 0; r < blind_plain_; r++) col[blind_plain_first_ + r] = rnd();
+      if (c < R) for (size_t p = 0; p < blind_pairs_; p++) { const u64 v = rnd(); col[blind_pair_first_ + 2 * p] = v; col[blind_pair_first_ + 2 * p + 1] = v; }
+    }
+  };
+  struct Joiner { std::thread t; void join() { if (t.joinable()) t.join(); } ~Joiner() { join(); } } bg;
+  if (zk_) bg.t = std::thread(zero_and_blind); else zero_and_blind();
   for (size_t i = 0; i < inputs_.size(); i++) {
     if (inputs[i] >= P) return "input target " + std::to_string(i) + " is not a canonical field element";
     if (!set(inputs_[i], inputs[i])) return err;
   }
+  std::unordered_map<u64, u64> inv_cache;
+  std::vector<u64> ptrace;                                            // per Poseidon row: row index, then wire columns 29..134
   for (const Op& op : ops_) {
     switch (op.kind) {
       case OP_CONST: set(op.out, op.k0); break;
       case OP_ARITH: { const u64 a = get(op.a), b = get(op.b), c = get(op.c); set(op.out, gl_add(gl_mul(op.k0, gl_mul(a, b)), gl_mul(op.k1, c))); break; }
-      case OP_INV: { const u64 a = get(op.a); set(op.out, a ? gl_inv(a) : 0); break; }
+      case OP_INV: {                                                 // is_equal hints: the differences repeat (index - j over all nodes), so inverses are cached
+        const u64 a = get(op.a); u64 r = 0;
+        if (a) { auto it = inv_cache.find(a); if (it != inv_cache.end()) r = it->second; else { r = gl_inv(a); inv_cache.emplace(a, r); } }
+        set(op.out, r); break;
+      }
       case OP_SPLIT: {
         const u64 x = get(op.out);
         if (x >> BASESUM_LIMBS) { if (err.empty()) err = "range check: " + std::to_string(x) + " does not fit " + std::to_string(BASESUM_LIMBS) + " binary limbs"; break; }
@@ -138,7 +198,8 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
       }
       case OP_POSEIDON: {                                           // targets of the row: inputs out..out+11, swap out+12, outputs out+13..out+24
         u64 st[12]; for (int i = 0; i < 12; i++) st[i] = get(op.out + i);
-        poseidon_permute(st);
+        ptrace.resize(ptrace.size() + 107); ptrace[ptrace.size() - 107] = op.row;
+        poseidon_permute_traced(st, ptrace.data() + ptrace.size() - 106);      // the row's S-box input wires, kept for the fill below
         for (int i = 0; i < 12; i++) set(op.out + 13 + i, st[i]);
         break;
       }
@@ -147,21 +208,17 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
   }
   for (size_t i = 0; i < public_inputs_.size(); i++) public_inputs[i] = get(public_inputs_[i]);
   if (!err.empty()) return err;
+  lap("ops");
 
-  memset(wires, 0, sizeof(u64) * (size_t)W * n);
-  for (Target t : wire_targets_) if (have[cls_[t]]) wires[(size_t)cells_[t].col * n + cells_[t].row] = val[cls_[t]];
-  for (size_t row = 0; row < gate_rows_; row++) if (row_kind_[row] == K_POSEIDON) {
-    u64 in[12]; for (int i = 0; i < 12; i++) in[i] = wires[(size_t)i * n + row];
-    poseidon_gate_row(wires, n, row, in, 0);
+  bg.join();                                                          // the matrix is zeroed (and its blinding rows written)
+  lap("join");
+  { const size_t m = fill_dst_.size(); const uint32_t* fd = fill_dst_.data(); const uint32_t* fc = fill_cls_.data(); const u64* vp = val.data();
+    for (size_t i = 0; i < m; i++) { if (i + 24 < m) __builtin_prefetch(vp + fc[i + 24]); const u64 v = vp[fc[i]]; wires[fd[i]] = v == UNSET ? 0 : v; } }      // classes never set hold 0
+  for (size_t off = 0; off < ptrace.size(); off += 107) {             // non-routed wires of the Poseidon rows (delta wires 25..28 stay 0: swap = 0)
+    const size_t row = (size_t)ptrace[off];
+    for (int i = 0; i < 106; i++) wires[(size_t)(29 + i) * n + row] = ptrace[off + 1 + i];
   }
-  if (zk_) {
-    if (!blinding_key) return "a zero-knowledge circuit needs a blinding key";
-    const SaltKey key = salt_key_from_bytes(blinding_key);
-    u64 blk[8]; u64 nblk = 0; int pos = 8;
-    auto rnd = [&]() { if (pos == 8) { salt_block(key, 0x626c696e64ULL /* "blind" */, nblk++, blk); pos = 0; } return blk[pos++]; };
-    for (size_t r = 0; r < blind_plain_; r++) for (int c = 0; c < W; c++) wires[(size_t)c * n + blind_plain_first_ + r] = rnd();
-    for (size_t p = 0; p < blind_pairs_; p++) for (int c = 0; c < R; c++) { const u64 v = rnd(); wires[(size_t)c * n + blind_pair_first_ + 2 * p] = v; wires[(size_t)c * n + blind_pair_first_ + 2 * p + 1] = v; }
-  }
+  lap("fill");
   return "";
 }
 

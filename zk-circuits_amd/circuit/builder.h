@@ -233,7 +233,7 @@ class Builder {
   // after build()
   size_t n_ = 0, gate_rows_ = 0, blind_plain_first_ = 0, blind_plain_ = 0, blind_pair_first_ = 0, blind_pairs_ = 0;
   std::vector<uint32_t> cls_; size_t ncls_ = 0;
-  std::vector<Target> wire_targets_;
+  std::vector<Target> wire_targets_; std::vector<uint32_t> fill_dst_, fill_cls_;
   std::vector<u64> constants_sigmas_, k_is_;
   std::vector<qpgpu_gate> gates_; std::vector<uint32_t> sel_idx_, groups_;
   qpgpu_circuit_desc desc_{};

@@ -162,15 +162,25 @@ static inline u64 dot11(const u64* a, const u64* x, u64 c0, u64 x0) {
   return d;
 }
 }
-inline void poseidon_permute(u64 st[12]) {
+// TRACE: also record the S-box inputs a PoseidonGate row carries (canonical): trace[0..36) = full rounds 1-3, [36..58) = the 22 partial
+// rounds' state[0], [58..106) = full rounds 26-29 — wire columns 29..134 in order. The partial-round S-box input is the same element in
+// the fast and the literal form (only the other eleven lanes live in another basis).
+template <bool TRACE>
+inline void poseidon_permute_impl(u64 st[12], u64* trace) {
   const u64* rc = POSEIDON_RC_HOST;
+  auto canon = [](u64 x) { return x - ((0 - (u64)(x >= GL_P)) & GL_P); };
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::addc(st[i], rc[i]);
   int r = 0;
-  for (; r < 4; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, r < 3 ? rc + 12 * (r + 1) : hostp::FAST_FIRST); }
+  for (; r < 4; r++) {
+    QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]);
+    hostp::mds_rc(st, r < 3 ? rc + 12 * (r + 1) : hostp::FAST_FIRST);
+    if (TRACE && r < 3) for (int i = 0; i < 12; i++) trace[12 * r + i] = canon(st[i]);
+  }
   { u64 t[11];
     for (int i = 0; i < 11; i++) t[i] = hostp::dot11(hostp::FAST_INIT[i], st + 1, 0, 0);
     for (int i = 0; i < 11; i++) st[1 + i] = t[i]; }
   for (int t = 0; t < 22; t++) {
+    if (TRACE) trace[36 + t] = canon(st[0]);
     const u64 s0 = hostp::addc(hostp::sbox(st[0]), hostp::FAST_Q[t]);
     const u64 d = hostp::dot11(hostp::FAST_WHAT[t], st + 1, 25, s0);
     QP_UNROLL_ALL for (int j = 0; j < 11; j++) {
@@ -180,11 +190,18 @@ inline void poseidon_permute(u64 st[12]) {
     st[0] = d;
   }
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::addc(st[i], rc[12 * 26 + i]);
-  for (r = 26; r < 29; r++) { QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]); hostp::mds_rc(st, rc + 12 * (r + 1)); }
+  for (r = 26; r < 29; r++) {
+    if (TRACE) for (int i = 0; i < 12; i++) trace[58 + 12 * (r - 26) + i] = canon(st[i]);
+    QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]);
+    hostp::mds_rc(st, rc + 12 * (r + 1));
+  }
+  if (TRACE) for (int i = 0; i < 12; i++) trace[58 + 36 + i] = canon(st[i]);
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] = hostp::sbox(st[i]);
   hostp::mds_rc(st, nullptr);
   QP_UNROLL_ALL for (int i = 0; i < 12; i++) st[i] -= (0 - (u64)(st[i] >= GL_P)) & GL_P;
 }
+inline void poseidon_permute(u64 st[12]) { poseidon_permute_impl<false>(st, nullptr); }
+inline void poseidon_permute_traced(u64 st[12], u64 trace[106]) { poseidon_permute_impl<true>(st, trace); }
 // literal round-by-round form (used by the witness synthesiser's traces and by tests)
 inline void poseidon_permute_generic(u64 st[12]) {
 #else

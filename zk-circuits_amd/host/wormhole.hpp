@@ -5,10 +5,13 @@
 //   WormholeProofAggregator   <- /root/reference/wormhole/aggregator/src/aggregator.rs:13-92 (push_proof / aggregate)
 //
 // Same call sequence and error behaviour as the reference (errors are std::runtime_error with the reference's text).
-// The circuit comes from the synthetic wormhole-shaped generator because plonky2's CircuitBuilder needs the Rust toolchain
-// (SURVEY.md §8d); a real deployment passes the descriptor built from ProverCircuitData instead.
+// Two circuit sources: the wormhole circuit built by libqpcircuit from the reference's circuit definition (include/qpcircuit.h:
+// CircuitConfig::standard_recursion[_zk]_config, committed with the reference's CircuitInputs), and the synthetic wormhole-shaped
+// generator (CircuitConfig::synthetic(preset), committed with a full witness: the bench shapes).
+// Link with -lqpgpu -lqpcircuit -lqpsynth.
 #pragma once
 #include "../../include/qpgpu.h"
+#include "../../include/qpcircuit.h"
 #include "../../include/qpsynth.h"
 #include <cstdint>
 #include <array>
@@ -23,9 +26,10 @@
 namespace wormhole {
 
 struct CircuitConfig {
-  bool zero_knowledge; const char* preset;
-  static CircuitConfig standard_recursion_config() { return {false, "A"}; }       // prover_tests.rs:11
-  static CircuitConfig standard_recursion_zk_config() { return {true, "B"}; }     // benches/prover.rs:12
+  bool zero_knowledge; const char* preset;    // preset == nullptr: the wormhole circuit itself (libqpcircuit)
+  static CircuitConfig standard_recursion_config() { return {false, nullptr}; }     // prover_tests.rs:11
+  static CircuitConfig standard_recursion_zk_config() { return {true, nullptr}; }   // benches/prover.rs:12
+  static CircuitConfig synthetic(const char* preset) { return {std::string(preset) == "B" || std::string(preset) == "TZ", preset}; }   // "A", "B", "T", ...
 };
 
 struct ProofWithPublicInputs {
@@ -34,7 +38,30 @@ struct ProofWithPublicInputs {
   const std::vector<uint8_t>& to_bytes() const { return bytes; }
 };
 
-struct CircuitInputs {                        // stand-in for wormhole_circuit::inputs::CircuitInputs: a full witness
+using Bytes32 = std::array<uint8_t, 32>;
+struct PublicCircuitInputs {                  // wormhole/circuit/src/inputs.rs:30-40
+  std::array<uint8_t, 16> funding_amount_le{}; Bytes32 nullifier{}, root_hash{}, exit_account{};
+  static PublicCircuitInputs try_from_slice(const std::vector<uint64_t>& pis) {       // inputs.rs:95-134
+    qpw_public_inputs o; PublicCircuitInputs r;
+    if (qpw_public_inputs_from_felts(pis.data(), pis.size(), &o) != 0) throw std::runtime_error(qpc_last_error());
+    memcpy(r.funding_amount_le.data(), o.funding_amount_le, 16); memcpy(r.nullifier.data(), o.nullifier, 32);
+    memcpy(r.root_hash.data(), o.root_hash, 32); memcpy(r.exit_account.data(), o.exit_account, 32);
+    return r;
+  }
+};
+struct PrivateCircuitInputs {                 // inputs.rs:43-55; storage_proof = ProcessedStorageProof (nodes + hex-digit child-hash indices)
+  Bytes32 secret{}; std::vector<std::vector<uint8_t>> storage_proof; std::vector<uint32_t> storage_proof_indices;
+  uint64_t transfer_count = 0; Bytes32 funding_account{}, unspendable_account{};
+};
+struct CircuitInputs { PublicCircuitInputs pub; PrivateCircuitInputs prv; };          // inputs.rs:23-27
+inline Bytes32 nullifier_from_preimage(const Bytes32& secret, uint64_t transfer_count) {            // Nullifier::from_preimage(..).hash
+  Bytes32 o; if (qpw_nullifier_from_preimage(secret.data(), 32, transfer_count, o.data()) != 0) throw std::runtime_error(qpc_last_error()); return o;
+}
+inline Bytes32 unspendable_account_from_secret(const Bytes32& secret) {                             // UnspendableAccount::from_secret(..).account_id
+  Bytes32 o; if (qpw_unspendable_account_from_secret(secret.data(), o.data()) != 0) throw std::runtime_error(qpc_last_error()); return o;
+}
+
+struct WitnessInputs {                        // a full witness (synthetic circuits; circuits loaded from a package)
   std::vector<uint64_t> wires;                // [num_wires][n], column-major
   std::vector<uint64_t> public_inputs;        // [16]
   // zk salts = ChaCha8(salt_key, salt_stream) on the device (include/qpgpu.h). test_inputs() uses the public test key with
@@ -45,27 +72,54 @@ struct CircuitInputs {                        // stand-in for wormhole_circuit::
     for (size_t i = 0; i < k.size(); i += 4) { uint32_t v = rd(); memcpy(&k[i], &v, 4); }
     return k;
   }
-  CircuitInputs() : salt_key(random_salt_key()) {}
+  WitnessInputs() : salt_key(random_salt_key()) {}
 };
 
 class CircuitData {                           // ProverCircuitData: resident on the GPU, shareable between provers
  public:
   CircuitData(const CircuitConfig& cfg, int device = 0) {
-    qpsynth_params p;
-    if (qpsynth_preset(cfg.preset, &p) != 0) throw std::runtime_error(qpsynth_last_error());
-    if (qpsynth_circuit_create(&p, &synth_) != 0) throw std::runtime_error(qpsynth_last_error());
-    desc_ = qpsynth_circuit_desc(synth_);
+    if (!cfg.preset) {                                          // WormholeCircuit::new(config).build_prover() (lib.rs:190-202)
+      if (qpc_circuit_build(QPC_WORMHOLE, cfg.zero_knowledge, &built_) != 0) throw std::runtime_error(qpc_last_error());
+      desc_ = qpc_circuit_desc(built_);
+    } else {
+      qpsynth_params p;
+      if (qpsynth_preset(cfg.preset, &p) != 0) throw std::runtime_error(qpsynth_last_error());
+      if (qpsynth_circuit_create(&p, &synth_) != 0) throw std::runtime_error(qpsynth_last_error());
+      desc_ = qpsynth_circuit_desc(synth_);
+    }
     if (qpgpu_ctx_create(device, &ctx_) != 0) throw std::runtime_error(qpgpu_last_error());
     if (qpgpu_circuit_create(ctx_, desc_, &circuit_) != 0) throw std::runtime_error(qpgpu_last_error());
   }
-  ~CircuitData() { if (circuit_) qpgpu_circuit_destroy(circuit_); if (ctx_) qpgpu_ctx_destroy(ctx_); if (synth_) qpsynth_circuit_destroy(synth_); }
+  ~CircuitData() { if (circuit_) qpgpu_circuit_destroy(circuit_); if (ctx_) qpgpu_ctx_destroy(ctx_); if (synth_) qpsynth_circuit_destroy(synth_); if (built_) qpc_circuit_destroy(built_); }
   CircuitData(const CircuitData&) = delete; CircuitData& operator=(const CircuitData&) = delete;
   const qpgpu_circuit_desc& common() const { return *desc_; }
   qpgpu_circuit* handle() const { return circuit_; }
   qpgpu_ctx* context() const { return ctx_; }
   size_t proof_size() const { return qpgpu_proof_size(circuit_); }
-  CircuitInputs test_inputs(uint64_t index = 0) const {     // CircuitInputs::test_inputs() analogue (seed 0x51570000 + index)
-    CircuitInputs in; size_t n = size_t(1) << desc_->degree_bits;
+  // commit() + generate_partial_witness for the built wormhole circuit: the reference's inputs -> full witness. Inputs that do not
+  // satisfy the statement throw with the conflict ("... set twice with different values").
+  WitnessInputs generate_witness(const CircuitInputs& ci) const {
+    if (!built_) throw std::runtime_error("this circuit was not built from the wormhole circuit definition");
+    qpw_circuit_inputs c{};
+    memcpy(c.funding_amount_le, ci.pub.funding_amount_le.data(), 16); memcpy(c.nullifier, ci.pub.nullifier.data(), 32);
+    memcpy(c.root_hash, ci.pub.root_hash.data(), 32); memcpy(c.exit_account, ci.pub.exit_account.data(), 32);
+    memcpy(c.secret, ci.prv.secret.data(), 32); c.transfer_count = ci.prv.transfer_count;
+    memcpy(c.funding_account, ci.prv.funding_account.data(), 32); memcpy(c.unspendable_account, ci.prv.unspendable_account.data(), 32);
+    if (ci.prv.storage_proof.size() != ci.prv.storage_proof_indices.size()) throw std::runtime_error("indices length must be equal to proof length");
+    std::vector<const uint8_t*> nodes; std::vector<uint32_t> lens;
+    for (const auto& nd : ci.prv.storage_proof) { nodes.push_back(nd.data()); lens.push_back((uint32_t)nd.size()); }
+    c.proof_len = (uint32_t)nodes.size(); c.proof_nodes = nodes.data(); c.proof_node_lens = lens.data(); c.proof_indices = ci.prv.storage_proof_indices.data();
+    std::vector<uint64_t> targets(qpc_circuit_num_inputs(built_)); size_t len = 0;
+    if (qpw_fill_targets(QPC_WORMHOLE, &c, targets.data(), targets.size(), &len) != 0) throw std::runtime_error(qpc_last_error());
+    WitnessInputs w; const size_t n = size_t(1) << desc_->degree_bits;                // fresh OS-RNG salt key; blinding rows from a second one
+    w.wires.resize((size_t)desc_->num_wires * n); w.public_inputs.resize(desc_->num_public_inputs);
+    const auto blinding = WitnessInputs::random_salt_key();
+    if (qpc_generate_witness(built_, targets.data(), len, blinding.data(), w.wires.data(), w.public_inputs.data()) != 0) throw std::runtime_error(qpc_last_error());
+    return w;
+  }
+  WitnessInputs test_inputs(uint64_t index = 0) const {     // synthetic circuits: the seeded witness (seed 0x51570000 + index)
+    if (!synth_) throw std::runtime_error("this circuit has no synthetic witness source");
+    WitnessInputs in; size_t n = size_t(1) << desc_->degree_bits;
     in.wires.resize((size_t)desc_->num_wires * n); in.public_inputs.resize(desc_->num_public_inputs);
     static const uint8_t test_key[32] = {QPSYNTH_TEST_SALT_KEY_BYTES};
     memcpy(in.salt_key.data(), test_key, 32); in.salt_stream = 0x51570000ULL + index;
@@ -73,7 +127,7 @@ class CircuitData {                           // ProverCircuitData: resident on 
     return in;
   }
  private:
-  qpsynth_circuit* synth_ = nullptr; const qpgpu_circuit_desc* desc_ = nullptr; qpgpu_ctx* ctx_ = nullptr; qpgpu_circuit* circuit_ = nullptr;
+  qpsynth_circuit* synth_ = nullptr; qpc_circuit* built_ = nullptr; const qpgpu_circuit_desc* desc_ = nullptr; qpgpu_ctx* ctx_ = nullptr; qpgpu_circuit* circuit_ = nullptr;
 };
 
 class WormholeProver {
@@ -81,8 +135,15 @@ class WormholeProver {
   explicit WormholeProver(std::shared_ptr<CircuitData> cd) : circuit_data(std::move(cd)), targets_(true) {}
   static WormholeProver create(const CircuitConfig& cfg, int device = 0) { return WormholeProver(std::make_shared<CircuitData>(cfg, device)); }  // lib.rs:190-202
 
-  // lib.rs:209-225 — single use: the targets are taken.
+  // lib.rs:209-225 — single use: the targets are taken. With the reference's CircuitInputs the witness is generated here; a statement
+  // that does not hold is reported by prove(), where upstream's witness generation fails.
   WormholeProver& commit(const CircuitInputs& inputs) {
+    if (!targets_) throw std::runtime_error("prover has already commited to inputs");
+    targets_ = false;
+    try { witness_ = circuit_data->generate_witness(inputs); } catch (const std::runtime_error& e) { witness_error_ = e.what(); }
+    return *this;
+  }
+  WormholeProver& commit(const WitnessInputs& inputs) {
     if (!targets_) throw std::runtime_error("prover has already commited to inputs");
     targets_ = false;
     const auto& d = circuit_data->common();
@@ -93,6 +154,7 @@ class WormholeProver {
   }
   // lib.rs:233-237 — consumes the witness.
   ProofWithPublicInputs prove() {
+    if (!witness_ && !witness_error_.empty()) throw std::runtime_error("Failed to prove: " + witness_error_);
     if (!witness_) throw std::runtime_error("Failed to prove: prover has not commited to any inputs");
     ProofWithPublicInputs out; out.bytes.resize(circuit_data->proof_size());
     qpgpu_prove_opts o{}; o.salt_key = witness_->salt_key.data(); o.salt_stream = witness_->salt_stream;
@@ -105,7 +167,7 @@ class WormholeProver {
   }
   std::shared_ptr<CircuitData> circuit_data;
  private:
-  bool targets_; std::optional<CircuitInputs> witness_;
+  bool targets_; std::optional<WitnessInputs> witness_; std::string witness_error_;
 };
 
 // wormhole/verifier/src/lib.rs:81-159 — VerifierCircuitData::verify through qpgpu_verify_batch (device Merkle openings, host algebra).
