@@ -31,7 +31,8 @@ enum {
   QPC_UNSPENDABLE_ACCOUNT = 2,  /* UnspendableAccount::circuit; no public inputs */
   QPC_STORAGE_PROOF = 3,        /* StorageProof::circuit; 8 public inputs (root hash, funding amount) */
   QPC_EXIT_ACCOUNT = 4,         /* SubstrateAccount::circuit (exit account as public input only); 4 public inputs */
-  QPC_VOTE = 5                  /* VoteCircuitData::circuit; 13 public inputs */
+  QPC_VOTE = 5,                 /* VoteCircuitData::circuit; 13 public inputs */
+  QPC_AGGREGATION = 6           /* a tree node: built by qpc_aggregation_circuit_build, not by qpc_circuit_build */
 };
 
 /* zero_knowledge: 0 = CircuitConfig::standard_recursion_config, 1 = standard_recursion_zk_config (blinding rows + salted oracles). */
@@ -84,6 +85,18 @@ typedef struct qpv_vote_inputs {
   uint32_t num_siblings, num_path_indices, actual_merkle_depth, reserved2;
 } qpv_vote_inputs;
 int qpv_fill_targets(const qpv_vote_inputs* in, uint64_t* inputs, size_t cap, size_t* len);
+
+/* ---- aggregation (wormhole/aggregator/src/circuits/tree.rs:106-143, aggregate_chunk): the circuit of one tree node — for each of
+ * `num_proofs` children of the circuit `inner` (a circuit of this library: leaf gate set, standard_recursion(_zk)_config), verify_proof
+ * in-circuit against verifier data given as (private) inputs, and the children's public inputs, concatenated, as the node's public inputs.
+ * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built from the leaf gate set: node circuits are
+ * not zk, and their layout is unpinned like every circuit here. */
+int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner, uint32_t num_proofs, qpc_circuit** out);
+/* set_verifier_data_target + set_proof_with_pis_target: the node circuit's input-target values from the inner circuit's verifier data
+ * (constants_sigmas_cap [2^cap_height][4], circuit_digest) and `count` proofs (ProofWithPublicInputs::to_bytes, `stride` bytes apart).
+ * *len = count of values; inputs may be NULL to query it. A proof that does not verify fails in qpc_generate_witness. */
+int qpc_aggregation_fill_targets(const qpc_circuit* c, const uint64_t* constants_sigmas_cap, const uint64_t circuit_digest[4], const uint8_t* proofs, size_t stride,
+                                 size_t proof_len, uint32_t count, uint64_t* inputs, size_t cap, size_t* len);
 
 /* PoseidonHash::hash_no_pad on the host (the hash all of the above use; csrc/poseidon.h). */
 void qpc_hash_no_pad(const uint64_t* felts, size_t count, uint64_t out[4]);

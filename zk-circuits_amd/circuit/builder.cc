@@ -198,9 +198,20 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
       }
       case OP_POSEIDON: {                                           // targets of the row: inputs out..out+11, swap out+12, outputs out+13..out+24
         u64 st[12]; for (int i = 0; i < 12; i++) st[i] = get(op.out + i);
-        ptrace.resize(ptrace.size() + 107); ptrace[ptrace.size() - 107] = op.row;
+        const u64 swap = get(op.out + 12);
+        if (swap > 1) { if (err.empty()) err = "Poseidon gate row " + std::to_string(op.row) + ": swap wire is not a bit"; break; }
+        if (swap) for (int i = 0; i < 4; i++) std::swap(st[i], st[i + 4]);
+        ptrace.resize(ptrace.size() + 108); ptrace[ptrace.size() - 108] = op.row; ptrace[ptrace.size() - 107] = swap;
         poseidon_permute_traced(st, ptrace.data() + ptrace.size() - 106);      // the row's S-box input wires, kept for the fill below
         for (int i = 0; i < 12; i++) set(op.out + 13 + i, st[i]);
+        break;
+      }
+      case OP_LOHI: { const u64 x = get(op.a); set(op.out, x & 0xFFFFFFFFULL); set(op.c, x >> 32); break; }
+      case OP_EXTINV: {                                             // (a + b*sqrt7)^-1 = (a - b*sqrt7) / (a^2 - 7 b^2)
+        const u64 a = get(op.a), b = get(op.b);
+        const u64 norm = gl_sub(gl_sqr(a), gl_mul(7, gl_sqr(b)));
+        const u64 ni = norm ? gl_inv(norm) : 0;
+        set(op.out, gl_mul(a, ni)); set(op.c, gl_mul(gl_sub(0, b), ni));
         break;
       }
     }
@@ -214,9 +225,10 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
   lap("join");
   { const size_t m = fill_dst_.size(); const uint32_t* fd = fill_dst_.data(); const uint32_t* fc = fill_cls_.data(); const u64* vp = val.data();
     for (size_t i = 0; i < m; i++) { if (i + 24 < m) __builtin_prefetch(vp + fc[i + 24]); const u64 v = vp[fc[i]]; wires[fd[i]] = v == UNSET ? 0 : v; } }      // classes never set hold 0
-  for (size_t off = 0; off < ptrace.size(); off += 107) {             // non-routed wires of the Poseidon rows (delta wires 25..28 stay 0: swap = 0)
+  for (size_t off = 0; off < ptrace.size(); off += 108) {             // non-routed wires of the Poseidon rows: delta = swap * (in[i+4] - in[i]), S-box inputs
     const size_t row = (size_t)ptrace[off];
-    for (int i = 0; i < 106; i++) wires[(size_t)(29 + i) * n + row] = ptrace[off + 1 + i];
+    if (ptrace[off + 1]) for (int i = 0; i < 4; i++) wires[(size_t)(25 + i) * n + row] = gl_sub(wires[(size_t)(4 + i) * n + row], wires[(size_t)i * n + row]);
+    for (int i = 0; i < 106; i++) wires[(size_t)(29 + i) * n + row] = ptrace[off + 2 + i];
   }
   lap("fill");
   return "";

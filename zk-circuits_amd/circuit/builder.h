@@ -152,6 +152,16 @@ class Builder {
     return BoolT{eq};
   }
 
+  // Hint: the inverse of a + b*sqrt(7) in F_{p^2} (0 for 0) as two virtual targets; the caller constrains it.
+  void ext_inverse_hint(Target a, Target b, Target& ia, Target& ib) {
+    ia = add_virtual(); ib = add_virtual();
+    ops_.push_back(Op{OP_EXTINV, ia, a, b, ib, 0, 0, 0});
+  }
+  // Hint: the low and high 32-bit halves of the canonical value of x; the caller constrains them.
+  void lohi_hint(Target x, Target& lo, Target& hi) { lo = add_virtual(); hi = add_virtual(); ops_.push_back(Op{OP_LOHI, lo, x, 0, hi, 0, 0, 0}); }
+  // Hint: the inverse of a base-field target (0 for 0); the caller constrains it.
+  Target inverse_hint(Target a) { Target inv = add_virtual(); ops_.push_back(Op{OP_INV, inv, a, 0, 0, 0, 0, 0}); return inv; }
+
   // Little-endian bits of x, which must be < 2^nbits: one BaseSum<2> row (wire 0 = sum, wires 1..63 = limbs, each constrained to {0,1});
   // limbs from nbits up are tied to zero.
   std::vector<BoolT> split_le(Target x, int nbits) {
@@ -164,12 +174,14 @@ class Builder {
   }
   void range_check(Target x, int nbits) { split_le(x, nbits); }
 
-  // Poseidon permutation on a gate row (swap = 0) and the no-padding sponge (rate 8, overwrite mode) over it.
-  void permute(Target st[12]) {
+  // Poseidon permutation on a gate row and the no-padding sponge (rate 8, overwrite mode) over it. With `swap` set the gate exchanges
+  // inputs 0..3 with 4..7 before permuting (the Merkle-path form: the bit says on which side the running digest sits).
+  void permute(Target st[12]) { permute_swap(st, BoolT{zero_}); }
+  void permute_swap(Target st[12], BoolT swap) {
     const uint32_t row = add_row(K_POSEIDON, 0, 0);
     const Target first = wire(row, 0);                      // targets of a fresh row are numbered in creation order: inputs first .. first+11,
     for (int i = 0; i < 12; i++) unite(wire(row, i), st[i]);
-    unite(wire(row, 24), zero_);                            // swap first+12,
+    unite(wire(row, 24), swap.t);                           // swap first+12,
     ops_.push_back(Op{OP_POSEIDON, first, 0, 0, 0, 0, 0, row});
     for (int i = 0; i < 12; i++) st[i] = wire(row, 12 + i); // outputs first+13 .. first+24
   }
@@ -197,7 +209,7 @@ class Builder {
   std::string generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const;
 
  private:
-  enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON };
+  enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON, OP_EXTINV, OP_LOHI };
   struct Op { uint8_t kind; Target out, a, b, c; u64 k0, k1; uint32_t row; };
   struct Cell { int32_t row; int16_t col; };
 

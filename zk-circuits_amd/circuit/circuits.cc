@@ -3,6 +3,7 @@
 // checks, same public inputs); gate placement is the builder's.
 #include "../../include/qpcircuit.h"
 #include "builder.h"
+#include "circuit_object.h"
 #include <cstring>
 #include <memory>
 
@@ -206,7 +207,7 @@ template <class F> int guard(F&& f) {
 }
 } // namespace
 
-struct qpc_circuit { uint32_t kind; Builder b; qpc_circuit(uint32_t k, bool zk) : kind(k), b(zk) {} };
+void qpc_set_error(const char* m) { g_err = m; }
 
 extern "C" {
 
@@ -233,7 +234,7 @@ size_t qpc_circuit_num_inputs(const qpc_circuit* c) { return c ? c->b.num_inputs
 void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]) { c->b.row_counts(out); out[6] = (uint32_t)c->b.num_gate_rows(); }
 
 int qpc_generate_witness(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs) { return guard([&]() -> int {
-  if (!c || !inputs || !wires || !public_inputs) return fail(QPGPU_ERR_ARG, "null argument");
+  if (!c || !inputs || !wires || (!public_inputs && c->b.desc().num_public_inputs)) return fail(QPGPU_ERR_ARG, "null argument");
   if (num_inputs != c->b.num_inputs()) return fail(QPGPU_ERR_ARG, "expected " + std::to_string(c->b.num_inputs()) + " input values, got " + std::to_string(num_inputs));
   const std::string e = c->b.generate(inputs, blinding_key, wires, public_inputs);
   if (!e.empty()) return fail(QPGPU_ERR_WITNESS, e);

@@ -192,7 +192,7 @@ class VoteInputsC(ctypes.Structure):
 
 
 QPGPU_ERR_WITNESS = -8
-QPC_WORMHOLE, QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_VOTE = range(6)
+QPC_WORMHOLE, QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_VOTE, QPC_AGGREGATION = range(7)
 _circuit = None
 
 
@@ -220,6 +220,9 @@ def circuit_lib():
         L.qpw_unspendable_account_from_secret.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.qpw_public_inputs_from_felts.argtypes = [u64p, ctypes.c_size_t, ctypes.POINTER(WormholePublicInputsC)]
         L.qpv_fill_targets.argtypes = [ctypes.POINTER(VoteInputsC), u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpc_aggregation_circuit_build.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpc_aggregation_fill_targets.argtypes = [ctypes.c_void_p, u64p, u64p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, u64p,
+                                                   ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.qpc_hash_no_pad.restype = None
         L.qpc_hash_no_pad.argtypes = [u64p, ctypes.c_size_t, u64p]
         _circuit = L
@@ -259,6 +262,36 @@ class BuiltCircuit:
         self.N = self.n << self.desc.fri_rate_bits
         self.W = self.desc.num_wires
         self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
+
+    @classmethod
+    def aggregation(cls, inner_desc, num_proofs):
+        """The circuit of one aggregation-tree node (aggregate_chunk, tree.rs:106-143): verifies `num_proofs` proofs of the circuit
+        `inner_desc` in-circuit and forwards their public inputs."""
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        circuit_check(circuit_lib().qpc_aggregation_circuit_build(ctypes.byref(inner_desc), num_proofs, ctypes.byref(h)))
+        self.handle, self.kind = h, QPC_AGGREGATION
+        self.desc = circuit_lib().qpc_circuit_desc(h).contents
+        self.n = 1 << self.desc.degree_bits
+        self.N = self.n << self.desc.fri_rate_bits
+        self.W = self.desc.num_wires
+        self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
+        self.num_proofs = num_proofs
+        return self
+
+    def aggregation_targets(self, constants_sigmas_cap, circuit_digest, proofs):
+        """set_verifier_data_target + set_proof_with_pis_target: the node circuit's input values from the inner circuit's verifier data and the
+        child proofs (bytes)."""
+        cap = np.ascontiguousarray(constants_sigmas_cap, dtype=np.uint64)
+        dig = np.ascontiguousarray(list(circuit_digest), dtype=np.uint64)
+        blob = b"".join(bytes(p) for p in proofs)
+        plen = len(proofs[0])
+        n = ctypes.c_size_t()
+        L = circuit_lib()
+        circuit_check(L.qpc_aggregation_fill_targets(self.handle, ptr(cap), ptr(dig), blob, plen, plen, len(proofs), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        circuit_check(L.qpc_aggregation_fill_targets(self.handle, ptr(cap), ptr(dig), blob, plen, plen, len(proofs), ptr(out), len(out), ctypes.byref(n)))
+        return out
 
     def row_counts(self):
         out = (ctypes.c_uint32 * 7)()
