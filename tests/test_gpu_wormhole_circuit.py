@@ -112,3 +112,44 @@ def test_vote_circuit_end_to_end():                               # voting/src/l
     bad = th.vote_test_inputs(); bad.private_inputs.actual_merkle_depth = 1                               # test_invalid_merkle_proof
     with pytest.raises(RuntimeError, match="Failed to prove"):
         pkg.WormholeProver.new(cfg).commit(bad).prove()
+
+
+def test_recursive_aggregation_tree_of_wormhole_proofs():
+    """recursive_aggregation_tree / pair_aggregation / public_inputs_are_aggregated (tree.rs:189-243) and aggregator_tests.rs:60-112 with
+    real recursion: four leaf proofs of the wormhole circuit (three inputs + the dummy), two levels of node circuits that verify their
+    children in-circuit, root proof verified; the root's public inputs are the leaves', in order; node proofs byte-equal to the oracle's."""
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_config())
+    agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, 2))
+    other = th.circuit_test_inputs(); other.public.exit_account = pkg.BytesDigest(bytes([7] * 32))
+    agg.prove_leaves([th.circuit_test_inputs(), other, th.circuit_test_inputs()], salt_seed=5)
+    prover = pkg.RecursiveChunkProver(cd)
+    root = agg.aggregate(chunk_prover=prover)
+    rcd = root.circuit_data
+    assert rcd.desc.degree_bits == 14 and rcd.desc.num_public_inputs == 64
+    pkg.WormholeVerifier.new(None, circuit_data=rcd).verify(root.proof)                       # root_proof.circuit_data.verify(root_proof.proof)
+    assert OracleCircuit(rcd.desc).verify(root.proof.to_bytes()) is None
+
+    class Agg:
+        public_inputs = root.proof.public_inputs
+    leaves = pkg.PublicCircuitInputs.try_from_aggregated(Agg, 16, 4)                          # aggregator_tests.rs: leaf public inputs in order
+    assert _expected(leaves[0]) and leaves[1].exit_account == bytes([7] * 32) and _expected(leaves[2]) and _expected(leaves[3])
+    # one level-0 node again, alone, against the oracle prover on the same witness
+    node_cd, inner, cap, digest = prover.level(0, 2)
+    leaf_a = pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove()
+    w, p = node_cd._built.witness(node_cd._built.aggregation_targets(cap, digest, [leaf_a.to_bytes(), leaf_a.to_bytes()]))
+    got = prover([leaf_a, leaf_a], 0).proof.to_bytes()
+    assert got == OracleCircuit(node_cd.desc).prove(w, p)
+    # a child that does not verify cannot be aggregated
+    bad = bytearray(leaf_a.to_bytes()); bad[-1] ^= 1
+    with pytest.raises(RuntimeError, match="child proof of this node does not verify"):
+        prover([leaf_a, bytes(bad)], 0)
+
+
+def test_recursive_aggregation_of_zk_leaves():
+    """Leaves under standard_recursion_zk_config (salted oracles, k = 14) aggregate through the same node circuits."""
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+    a = pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove()
+    b = pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove()
+    node = pkg.RecursiveChunkProver(cd)([a, b], 0)
+    pkg.WormholeVerifier.new(None, circuit_data=node.circuit_data).verify(node.proof)
+    assert node.proof.public_inputs == a.public_inputs + b.public_inputs

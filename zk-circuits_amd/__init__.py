@@ -17,4 +17,4 @@ from .inputs import (BytesDigest, CircuitInputs, PublicCircuitInputs, PrivateCir
 from .verifier import WormholeVerifier  # noqa: F401
 from .circuit_builder import generate_circuit_binaries  # noqa: F401
 from .aggregator import (WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves, AggregatedProof,  # noqa: F401
-                         aggregate_to_tree, aggregate_level, aggregate_to_tree_distributed, gather_proofs)
+                         aggregate_to_tree, aggregate_level, aggregate_to_tree_distributed, gather_proofs, RecursiveChunkProver)

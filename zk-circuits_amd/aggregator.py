@@ -2,11 +2,11 @@
 circuits/tree.rs:24-103, util.rs:11-29).
 
 Scope: the buffer semantics and error behaviour of push_proof / aggregate, the sharding of
-independent leaf proofs (one per GPU stream / per rank) and the RCCL gather of the fixed-size proof blobs that precedes the
-aggregator step. The device path proves recursion circuits too (all gates of the in-circuit verifier are evaluated by the
-quotient kernel), but the recursive-verifier circuit and its witness are built by qp-plonky2's Rust
-CircuitBuilder / generators on the host (tree.rs:106-135), which this image cannot run; so `aggregate()` here returns the
-gathered, padded leaf set — exactly what `aggregate_level` (tree.rs:92-103) consumes — rather than a root proof.
+independent leaf proofs (one per GPU stream / per rank), the RCCL gather of the fixed-size proof blobs that precedes the
+aggregator step, and the aggregation tree itself: `RecursiveChunkProver` is aggregate_chunk (tree.rs:106-143) — the node circuit
+verifies its children in-circuit (libqpcircuit's own recursive verifier on the leaf gate set, include/qpcircuit.h; qp-plonky2's is not
+on disk, so node circuits are this repo's layout, not upstream's), its witness is generated on the host and proved on the device.
+`aggregate()` returns the padded leaf set without a chunk prover and the root proof with one.
 """
 import ctypes
 import os
@@ -141,6 +141,68 @@ class AggregatedProof:
     def __init__(self, proof, circuit_data=None):
         self.proof = proof
         self.circuit_data = circuit_data
+
+
+class RecursiveChunkProver:
+    """aggregate_chunk (tree.rs:106-143) with the device as prover: for the children's circuit build the node circuit
+    (add_virtual_verifier_data, add_virtual_proof_with_pis + verify_proof + register_public_inputs per child), set the verifier-data and
+    proof targets, generate the witness (host threads, one node each) and prove the whole level as one device batch. The reference rebuilds
+    the node circuit for every chunk (tree.rs:112-128); every chunk of a level has the same circuit, so it is built once per level here.
+    Level 0 takes proofs of `leaf_circuit_data`; level k takes proofs of level k-1's node circuit."""
+
+    def __init__(self, leaf_circuit_data, device=0):
+        self.leaf = leaf_circuit_data
+        self.device = device
+        self._levels = {}               # (level, children per node) -> (WormholeCircuitData of the node circuit, inner circuit data, its cap, its digest)
+        self._level_width = {}          # level -> children per node of the (full) chunks proved at that level
+
+    def level(self, level, width):
+        from .prover import WormholeCircuitData
+        key = (level, width)
+        if key not in self._levels:
+            inner = self.leaf if level == 0 else self.level(level - 1, self._level_width.get(level - 1, width))[0]
+            node = ffi.BuiltCircuit.aggregation(inner.desc, width)
+            self._levels[key] = (WormholeCircuitData.from_built(node, self.device), inner, inner.constants_sigmas_cap(), list(inner.desc.circuit_digest))
+        return self._levels[key]
+
+    def prove_chunks(self, chunks, level):
+        if not chunks:
+            return []
+        width = len(chunks[0])
+        if any(len(c) != width for c in chunks):            # a ragged last chunk gets its own (narrower) circuit, as in the reference
+            return [self.prove_chunks([c], level)[0] for c in chunks]
+        self._level_width.setdefault(level, width)
+        cd, inner, cap, digest = self.level(level, width)
+        node = cd._built
+
+        def witness(chunk):
+            raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunk]
+            try:
+                return node.witness(node.aggregation_targets(cap, digest, raw))
+            except ffi.CircuitError as e:
+                raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
+        if len(chunks) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(chunks), max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
+                wit = list(ex.map(witness, chunks))
+        else:
+            wit = [witness(chunks[0])]
+        b = len(wit)
+        wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w, _ in wit])
+        pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
+        o = ffi.ProveOpts()                                  # node circuits are not zk: no salts
+        buf = ctypes.create_string_buffer(cd.proof_size * b)
+        lens = (ctypes.c_size_t * b)()
+        ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf, cd.proof_size, lens))
+        return [AggregatedProof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs), cd)
+                for i in range(b)]
+
+    def __call__(self, chunk, level):
+        return self.prove_chunks([chunk], level)[0]
+
+    def proof_size_of_level(self, level, width=DEFAULT_TREE_BRANCHING_FACTOR):
+        """Byte size of the proofs that ENTER `level` (aggregate_to_tree_distributed's exchange size)."""
+        return self.leaf.proof_size if level == 0 else self.level(level - 1, width)[0].proof_size
 
 
 def aggregate_level(proofs, chunk_prover, config, level):

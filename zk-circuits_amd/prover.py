@@ -124,6 +124,24 @@ class WormholeCircuitData:
         self.proof_size = L.qpgpu_proof_size(self._circuit)
         return self
 
+    @classmethod
+    def from_built(cls, built, device=0):
+        """Resident circuit from an ffi.BuiltCircuit (e.g. an aggregation node circuit)."""
+        self = cls.__new__(cls)
+        self.config = None
+        self._synth, self._built = None, built
+        self.desc = built.desc
+        self.n = 1 << self.desc.degree_bits
+        self.num_wires = self.desc.num_wires
+        self.num_public_inputs = self.desc.num_public_inputs
+        L = ffi.lib()
+        self._ctx = ctypes.c_void_p()
+        ffi.check(L.qpgpu_ctx_create(device, ctypes.byref(self._ctx)))
+        self._circuit = ctypes.c_void_p()
+        ffi.check(L.qpgpu_circuit_create(self._ctx, ctypes.byref(self.desc), ctypes.byref(self._circuit)))
+        self.proof_size = L.qpgpu_proof_size(self._circuit)
+        return self
+
     def common_bytes(self):
         return ffi.write_common(self.desc)
 
