@@ -278,51 +278,46 @@ def main():
             real = {"error": repr(e)}
 
     # ---- extra, NOT the headline: an aggregation tree over 64 leaves per GPU (BASELINE configs[2]/[3] flavour).
-    # Leaves: one qpgpu_prove_batch of this preset. Nodes: level by level (tree.rs:56-103), every level one device batch of proofs of
-    # a recursion-shaped circuit (all 14 gate types, 2^13 rows). The node witnesses come from a small pre-generated pool picked by a hash
-    # of the children — a STAND-IN for qp-plonky2's recursive-verifier witness generator (Rust host code): the timing is that of
-    # the device work of aggregate(), the root proves nothing about the leaves. With N > 1 ranks the top levels exchange fixed-size
-    # proof blobs over RCCL (aggregate_to_tree_distributed).
+    # Leaves: one qpgpu_prove_batch of this preset. Nodes: aggregate_chunk (tree.rs:106-143) for real — every node circuit verifies its two
+    # children in-circuit (libqpcircuit's recursive verifier on the leaf gate set, include/qpcircuit.h; 2^14 rows per node), its witness is
+    # generated on host threads and each level is proved as one device batch (aggregator.RecursiveChunkProver); level by level as
+    # tree.rs:56-103. The root proof is verified. Node circuits are this repo's own layout (qp-plonky2's recursive verifier is not on disk).
+    # With N > 1 ranks the top levels exchange fixed-size proof blobs over RCCL (aggregate_to_tree_distributed).
     tree = None
     tree_leaves, tree_root, tree_desc_owner = None, None, None
     if args.batch == 1 and not args.no_tree and args.preset in ("A", "B"):
         try:
-            import hashlib, importlib
+            import importlib
             agg = importlib.import_module("zk-circuits_amd.aggregator")
             leaves_per_rank = 64
-            setup_ok, pool, gcR = 1, [], None
-            try:
-                scR = H.SynthCircuit("R"); gcR = H.GpuCircuit(scR.desc, device=local_rank)
-                for i in range(4):
-                    w, p = scR.witness(7000 + rank * 16 + i)
-                    pool.append((torch.from_numpy(w.view(np.int64)).to(dev), p))
+
+            class LeafData:                                       # what RecursiveChunkProver needs of the leaf circuit
+                desc = sc.desc; proof_size = gc.proof_size
+                def constants_sigmas_cap(self):
+                    return gc.cap()
+            depth = int(round(np.log2(leaves_per_rank * world)))
+            cfg = agg.TreeAggregationConfig(2, depth)
+            ptrs = [wit_dev[j % nwit].data_ptr() for j in range(leaves_per_rank)]
+            pl = [pis_list[j % nwit] for j in range(leaves_per_rank)]
+            np_ = agg.RecursiveChunkProver(LeafData(), device=local_rank)
+            setup_ok = 1
+            try:                                                  # untimed: build the node circuit of every level (once per circuit) and warm the workspaces
+                t_build = time.perf_counter()
+                warm = gc.prove_batch(ptrs[:2], pl[:2], salt_seed=seeds[0], wires_on_device=True)
+                for lvl in range(depth):
+                    warm = [np_([warm[0], warm[-1]], lvl).proof.to_bytes()] * 2
+                t_build = time.perf_counter() - t_build
             except Exception:
                 setup_ok = 0
             if dist is not None:                                  # all ranks enter the collectives below, or none does
                 t = torch.tensor([setup_ok], dtype=torch.int32, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN); setup_ok = int(t.item())
             if not setup_ok:
                 raise RuntimeError("aggregation-tree setup failed on a rank")
-
-            class NodeProver:
-                def pick(self, chunk):
-                    return pool[hashlib.sha256(chunk[0][:64] + chunk[-1][-64:]).digest()[0] % len(pool)]
-                def prove_chunks(self, chunks, level):
-                    sel = [self.pick(c) for c in chunks]
-                    out = gcR.prove_batch([s[0].data_ptr() for s in sel], [s[1] for s in sel], salt_seed=level, wires_on_device=True)
-                    return [agg.AggregatedProof(o) for o in out]
-                def __call__(self, chunk, level):
-                    return self.prove_chunks([chunk], level)[0]
-            depth = int(round(np.log2(leaves_per_rank * world)))
-            cfg = agg.TreeAggregationConfig(2, depth)
-            ptrs = [wit_dev[j % nwit].data_ptr() for j in range(leaves_per_rank)]
-            pl = [pis_list[j % nwit] for j in range(leaves_per_rank)]
-            np_ = NodeProver()
-            np_.prove_chunks([[b"\0" * 64, b"\0" * 64]] * 4, 0)               # warm the node circuit's workspaces
             barrier(); t3 = time.perf_counter()
             leaf_proofs = gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True)
             barrier(); t4 = time.perf_counter()
             if dist is not None:
-                root = agg.aggregate_to_tree_distributed(leaf_proofs, cfg, np_, lambda lvl: gc.proof_size if lvl == 0 else gcR.proof_size, device=(dev if backend == "nccl" else None))
+                root = agg.aggregate_to_tree_distributed(leaf_proofs, cfg, np_, np_.proof_size_of_level, device=(dev if backend == "nccl" else None))
             else:
                 root = agg.aggregate_to_tree(leaf_proofs, cfg, np_)
             barrier(); t5 = time.perf_counter()
@@ -330,25 +325,37 @@ def main():
             if dist is not None:
                 t = torch.tensor([tl, tt], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX); tl, tt = float(t[0]), float(t[1])
             n_leaves = leaves_per_rank * world
+            root_cd = np_.level(depth - 1, 2)[0]
             tree = {"leaves": n_leaves, "branching": 2, "levels": depth, "nodes": n_leaves - 1,
                     "leaf_stage_s": round(tl, 4), "leaf_proofs_per_s": round(n_leaves / tl, 1),
                     "tree_stage_s": round(tt, 4), "total_s": round(tl + tt, 4), "root_bytes": len(root.proof),
-                    "note": "node witnesses from a pre-generated pool (stand-in for the Rust recursive-verifier witness generator); "
-                            "device work of aggregate() only"}
-            # the reference's aggregator bench matrix (wormhole/aggregator/benches/aggregator.rs:107-130): aggregate() over b^d ready-made
-            # leaf proofs, (b, d) in {(2,1..5), (3..7,2)} — the same stand-in node circuit for every b (the real node circuit grows with b)
+                    "root_public_inputs": int(root_cd.num_public_inputs), "node_circuit_rows": root_cd._built.row_counts()["rows_in_use"],
+                    "node_circuit_degree_bits": int(root_cd.desc.degree_bits), "node_circuits_build_s": round(t_build, 2),
+                    "note": "real recursion: every node verifies its children in-circuit (this repo's recursive verifier on the leaf gate set); "
+                            "tree_stage_s = host witness generation (threads) + one device batch per level"}
             if dist is None:
-                matrix = []
+                rver = H.GpuVerifier(root_cd.desc, root_cd.constants_sigmas_cap(), device=local_rank)
+                tree["root_verified"] = bool(rver.verify(root.proof.to_bytes()) is None)
+                tree["root_public_inputs_are_the_leaves"] = bool(list(root.proof.public_inputs) == [int(x) for pf in leaf_proofs for x in np.frombuffer(pf[-128:], dtype="<u8")])
+                rver.close()
+            # the reference's aggregator bench matrix (wormhole/aggregator/benches/aggregator.rs:107-130): aggregate() over b^d ready-made leaf
+            # proofs, (b, d) in {(2,1..5), (3..7,2)}, node circuits built beforehand (the reference rebuilds them per chunk inside the timing)
+            if dist is None:
+                matrix, t_m0 = [], time.perf_counter()
                 for b_, d_ in [(2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]:
+                    if time.perf_counter() - t_m0 > 90:
+                        matrix.append({"branching": b_, "depth": d_, "skipped": "matrix time box (90 s) reached"}); continue
                     cfg_ = agg.TreeAggregationConfig(b_, d_)
                     lv = leaf_proofs[:cfg_.num_leaf_proofs]
-                    agg.aggregate_to_tree(lv, cfg_, np_)                               # warm
+                    pr_ = np_ if b_ == 2 else agg.RecursiveChunkProver(LeafData(), device=local_rank)
+                    r_ = agg.aggregate_to_tree(lv, cfg_, pr_)                          # builds (b > 2) and warms
                     torch.cuda.synchronize(); ta = time.perf_counter()
-                    for _ in range(3):
-                        agg.aggregate_to_tree(lv, cfg_, np_)
-                    torch.cuda.synchronize(); tb = (time.perf_counter() - ta) / 3
+                    reps_ = 2
+                    for _ in range(reps_):
+                        r_ = agg.aggregate_to_tree(lv, cfg_, pr_)
+                    torch.cuda.synchronize(); tb = (time.perf_counter() - ta) / reps_
                     matrix.append({"branching": b_, "depth": d_, "leaves": cfg_.num_leaf_proofs, "nodes": sum(b_ ** k for k in range(d_)),
-                                   "aggregate_ms": round(tb * 1e3, 3)})
+                                   "node_degree_bits": int(r_.circuit_data.desc.degree_bits), "aggregate_ms": round(tb * 1e3, 3)})
                 tree["bench_matrix"] = matrix
             # the aggregator's intake check: all 64 leaf proofs through the product's batch verifier (device Merkle openings + host algebra)
             try:
@@ -362,10 +369,9 @@ def main():
             except Exception as e:
                 tree["leaf_batch_verify"] = {"error": repr(e)[:160]}
             to_check += [("tree_leaf_first", leaf_proofs[0], 0, seeds[0]), ("tree_leaf_last", leaf_proofs[-1], (leaves_per_rank - 1) % nwit, seeds[0] + leaves_per_rank - 1)]
-            tree_leaves, tree_root, tree_desc_owner = leaf_proofs, root.proof, scR
-            gcR.close()
+            tree_leaves, tree_root, tree_desc_owner = leaf_proofs, root.proof.to_bytes(), root_cd
         except Exception as e:                                  # never let the extra measurement take the headline down
-            tree = {"error": repr(e)[:200]}
+            tree = {"error": repr(e)[:300]}
 
     # Poseidon throughput of the dominant kernel against the VALU issue ceiling. Both ceilings come from a committed
     # file: the first-principles bound (static ISA instruction counts x 2 or 4 issue cycles, tools/poseidon_issue_bound.py) and the

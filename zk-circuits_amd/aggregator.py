@@ -114,6 +114,7 @@ def gather_proofs(local_proofs, proof_size, group=None, device=None):
     import torch
     import torch.distributed as dist
     k = len(local_proofs)
+    local_proofs = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in local_proofs]
     flat = np.frombuffer(b"".join(local_proofs), dtype=np.uint8).copy() if k else np.zeros(0, dtype=np.uint8)
     t = torch.from_numpy(flat)
     if device is not None:
