@@ -89,8 +89,9 @@ int qpv_fill_targets(const qpv_vote_inputs* in, uint64_t* inputs, size_t cap, si
 /* ---- aggregation (wormhole/aggregator/src/circuits/tree.rs:106-143, aggregate_chunk): the circuit of one tree node — for each of
  * `num_proofs` children of the circuit `inner` (a circuit of this library: leaf gate set, standard_recursion(_zk)_config), verify_proof
  * in-circuit against verifier data given as (private) inputs, and the children's public inputs, concatenated, as the node's public inputs.
- * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built from the leaf gate set: node circuits are
- * not zk, and their layout is unpinned like every circuit here. */
+ * The node circuit takes the inner circuit's config (tree.rs:111): zero-knowledge children give a zero-knowledge node.
+ * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built from the leaf gate set; its layout is
+ * unpinned like every circuit here. */
 int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner, uint32_t num_proofs, qpc_circuit** out);
 /* set_verifier_data_target + set_proof_with_pis_target: the node circuit's input-target values from the inner circuit's verifier data
  * (constants_sigmas_cap [2^cap_height][4], circuit_digest) and `count` proofs (ProofWithPublicInputs::to_bytes, `stride` bytes apart).

@@ -83,6 +83,21 @@ def test_a_child_that_does_not_verify_cannot_be_witnessed(vote_leaf, level1):
         node.witness(node.aggregation_targets(oc.cap(), wrong_digest, [leaf, leaf]))
 
 
+def test_zero_knowledge_children_give_a_zero_knowledge_node():
+    """aggregate_chunk builds the node with the children's config (tree.rs:111); WormholeProofAggregator::default is the zk config
+    (aggregator.rs:20-23). A zk node has blinding rows (2^15 rows for two children) and its proof carries salts."""
+    inner = BuiltCircuit(QPC_VOTE, True); oc = OracleCircuit(inner.desc)
+    w, p = inner.witness(th.vote_test_inputs().fill_targets(), bytes(range(32)))
+    leaf = oc.prove(w, p, salts=SynthCircuit("B").salts_keyed(TEST_SALT_KEY, 1))
+    node = BuiltCircuit.aggregation(inner.desc, 2); on = OracleCircuit(node.desc)
+    assert node.desc.zero_knowledge == 1 and node.desc.degree_bits == 15
+    x = node.aggregation_targets(oc.cap(), inner.desc.circuit_digest, [leaf, leaf])
+    with pytest.raises(CircuitError, match="blinding key"):
+        node.witness(x)
+    w1, p1 = node.witness(x, bytes(range(32)))
+    assert check_witness(on, w1, p1) is None and list(p1) == list(p) * 2
+
+
 def test_argument_errors(vote_leaf, level1):
     inner, oc, leaf, p = vote_leaf
     node, on, w, pis = level1

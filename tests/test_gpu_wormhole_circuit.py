@@ -150,6 +150,14 @@ def test_recursive_aggregation_of_zk_leaves():
     cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
     a = pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove()
     b = pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove()
-    node = pkg.RecursiveChunkProver(cd)([a, b], 0)
-    pkg.WormholeVerifier.new(None, circuit_data=node.circuit_data).verify(node.proof)
+    prover = pkg.RecursiveChunkProver(cd)
+    node = prover([a, b], 0)
+    ncd = node.circuit_data
+    assert ncd.desc.zero_knowledge == 1 and ncd.desc.degree_bits == 15          # CircuitBuilder::new(common_data.config.clone()): zk children, zk node
+    pkg.WormholeVerifier.new(None, circuit_data=ncd).verify(node.proof)
     assert node.proof.public_inputs == a.public_inputs + b.public_inputs
+    again = prover([a, b], 0)
+    assert again.proof.to_bytes() != node.proof.to_bytes()                      # fresh blinding rows and salts
+    root = prover([node.proof, again.proof], 1)                                 # a zk node verifies zk nodes
+    assert root.circuit_data.desc.degree_bits == 15 and len(root.proof.public_inputs) == 64
+    pkg.WormholeVerifier.new(None, circuit_data=root.circuit_data).verify(root.proof)

@@ -151,9 +151,12 @@ class RecursiveChunkProver:
     the node circuit for every chunk (tree.rs:112-128); every chunk of a level has the same circuit, so it is built once per level here.
     Level 0 takes proofs of `leaf_circuit_data`; level k takes proofs of level k-1's node circuit."""
 
-    def __init__(self, leaf_circuit_data, device=0):
+    def __init__(self, leaf_circuit_data, device=0, salt_seed=None):
+        """`salt_seed` (tests, benches): zero-knowledge node circuits take their blinding rows and salts from the public test key with
+        reproducible streams; without it both come from the OS RNG, fresh per level."""
         self.leaf = leaf_circuit_data
         self.device = device
+        self.salt_seed = salt_seed
         self._levels = {}               # (level, children per node) -> (WormholeCircuitData of the node circuit, inner circuit data, its cap, its digest)
         self._level_width = {}          # level -> children per node of the (full) chunks proved at that level
 
@@ -176,10 +179,13 @@ class RecursiveChunkProver:
         cd, inner, cap, digest = self.level(level, width)
         node = cd._built
 
+        zk = bool(cd.desc.zero_knowledge)                 # a node takes its children's config (tree.rs:111)
+        blinding_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
+
         def witness(chunk):
             raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunk]
             try:
-                return node.witness(node.aggregation_targets(cap, digest, raw))
+                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key)
             except ffi.CircuitError as e:
                 raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
         if len(chunks) > 1:
@@ -191,7 +197,10 @@ class RecursiveChunkProver:
         b = len(wit)
         wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w, _ in wit])
         pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
-        o = ffi.ProveOpts()                                  # node circuits are not zk: no salts
+        o = ffi.ProveOpts()
+        if zk:
+            key, o.salt_stream = (ffi.TEST_SALT_KEY, self.salt_seed + (level << 20)) if self.salt_seed is not None else (os.urandom(32), 0)
+            keep = ffi.set_salt_key(o, key)      # noqa: F841
         buf = ctypes.create_string_buffer(cd.proof_size * b)
         lens = (ctypes.c_size_t * b)()
         ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf, cd.proof_size, lens))

@@ -225,11 +225,15 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
   lap("join");
   { const size_t m = fill_dst_.size(); const uint32_t* fd = fill_dst_.data(); const uint32_t* fc = fill_cls_.data(); const u64* vp = val.data();
     for (size_t i = 0; i < m; i++) { if (i + 24 < m) __builtin_prefetch(vp + fc[i + 24]); const u64 v = vp[fc[i]]; wires[fd[i]] = v == UNSET ? 0 : v; } }      // classes never set hold 0
-  for (size_t off = 0; off < ptrace.size(); off += 108) {             // non-routed wires of the Poseidon rows: delta = swap * (in[i+4] - in[i]), S-box inputs
-    const size_t row = (size_t)ptrace[off];
-    if (ptrace[off + 1]) for (int i = 0; i < 4; i++) wires[(size_t)(25 + i) * n + row] = gl_sub(wires[(size_t)(4 + i) * n + row], wires[(size_t)i * n + row]);
-    for (int i = 0; i < 106; i++) wires[(size_t)(29 + i) * n + row] = ptrace[off + 2 + i];
-  }
+  { const size_t np = ptrace.size() / 108;                             // non-routed wires of the Poseidon rows, column by column (sequential writes):
+    for (size_t r = 0; r < np; r++) if (ptrace[r * 108 + 1]) {         // delta = swap * (in[i+4] - in[i]),
+      const size_t row = (size_t)ptrace[r * 108];
+      for (int i = 0; i < 4; i++) wires[(size_t)(25 + i) * n + row] = gl_sub(wires[(size_t)(4 + i) * n + row], wires[(size_t)i * n + row]);
+    }
+    for (int i = 0; i < 106; i++) {                                    // the S-box inputs
+      u64* col = wires + (size_t)(29 + i) * n;
+      for (size_t r = 0; r < np; r++) col[(size_t)ptrace[r * 108]] = ptrace[r * 108 + 2 + i];
+    } }
   lap("fill");
   return "";
 }

@@ -6,7 +6,7 @@
 // a gate-for-gate restatement of this repo's host verifier (csrc/verify.hip: transcript, vanishing identity at zeta, FRI openings, folds and
 // Merkle paths; formulas SURVEY.md App. A.4-A.9) on the builder's leaf gate set (Poseidon / Arithmetic / BaseSum / Constant): extension-field
 // products are four Arithmetic slots, Merkle steps use the Poseidon gate's swap wire, table look-ups are indicator sums. A node circuit is
-// therefore larger than upstream's (2^14 rows for two children instead of ~2^12-2^13), its layout is unpinned like every circuit of this
+// therefore larger than upstream's (2^14 rows for two children, 2^15 with zero knowledge, instead of ~2^12-2^13), its layout is unpinned like every circuit of this
 // builder, and what it proves is the same: "each child proof verifies against the given verifier data, and these are their public inputs".
 // The inner circuit must use the leaf gate set (a leaf circuit or another node circuit built here).
 #include "../../include/qpcircuit.h"
@@ -380,7 +380,7 @@ extern "C" int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner_des
     AggInfo* info = new AggInfo(); info->count = num_proofs;
     const std::string e = info->inner.init(*inner_desc);
     if (!e.empty()) { delete info; qpc_internal_set_error(e.c_str()); return QPGPU_ERR_ARG; }
-    qpc_circuit* c = qpc_internal_new_circuit(QPC_AGGREGATION, false);          // aggregate_chunk builds with the inner circuit's config; node circuits are not zk
+    qpc_circuit* c = qpc_internal_new_circuit(QPC_AGGREGATION, inner_desc->zero_knowledge != 0);   // CircuitBuilder::new(common_data.config.clone()) (tree.rs:111): zk leaves give zk nodes
     qpc_internal_set_aux(c, info, [](void* p) { delete (AggInfo*)p; });
     Builder& b = *qpc_internal_builder(c);
     const VerifierDataT vd = add_verifier_data_targets(b, info->inner);         // tree.rs:113-114
