@@ -152,3 +152,64 @@ def test_gloo_world8_distributed_tree_schedule(tmp_path):
                         "--master-port", "29613", str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 8
+
+
+def test_gloo_world2_tree_with_real_node_circuits(tmp_path):
+    """The distributed tree with real recursion on CPU: each of two gloo ranks holds two leaf proofs (vote circuit), proves its level-0 node
+    locally, the two node proofs are gathered and rank 0 proves the root. Node circuits are libqpcircuit's (in-circuit verification of the
+    children); the oracle stands in for the device as prover (test infrastructure). Every rank gets the root, it verifies, and its public
+    inputs are the four leaves' in rank order."""
+    script = tmp_path / "t.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        import torch.distributed as dist
+        from harness import *
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        agg = importlib.import_module("zk-circuits_amd.aggregator")
+        th = importlib.import_module("zk-circuits_amd.test_helpers")
+        ffi = importlib.import_module("zk-circuits_amd.ffi")
+        hash_no_pad = ffi.hash_no_pad
+        inner = BuiltCircuit(QPC_VOTE, False); oc = OracleCircuit(inner.desc)
+        leaves = []
+        for i in range(2):                                           # two different voters per rank: ranks differ by proposal id
+            ci = th.vote_test_inputs()
+            ci.public_inputs.proposal_id = [rank + 1, i + 1, 0, 9]
+            ci.public_inputs.nullifier = [int(v) for v in hash_no_pad([int(v) for v in hash_no_pad(ci.private_inputs.private_key)] + ci.public_inputs.proposal_id)]
+            w, p = inner.witness(ci.fill_targets()); leaves.append(oc.prove(w, p, threads=3))
+
+        class OracleChunkProver:                                     # aggregate_chunk with the oracle as prover (the product uses the device)
+            def __init__(self):
+                self.levels = {}
+            def level(self, lvl):
+                if lvl not in self.levels:
+                    below = (inner, oc) if lvl == 0 else self.level(lvl - 1)
+                    node = BuiltCircuit.aggregation(below[0].desc, 2)
+                    self.levels[lvl] = (node, OracleCircuit(node.desc))
+                return self.levels[lvl]
+            def __call__(self, chunk, lvl):
+                below = (inner, oc) if lvl == 0 else self.level(lvl - 1)
+                node, on = self.level(lvl)
+                w, p = node.witness(node.aggregation_targets(below[1].cap(), below[0].desc.circuit_digest, [bytes(c) for c in chunk]))
+                return agg.AggregatedProof(on.prove(w, p, threads=3))
+        pr = OracleChunkProver()
+        def size_of(lvl):                                            # bytes of the proofs that enter level lvl
+            return len(leaves[0]) if lvl == 0 else ffi.proof_size_of(pr.level(lvl - 1)[0].desc)
+        cfg = agg.TreeAggregationConfig(2, 2)
+        root = agg.aggregate_to_tree_distributed(leaves, cfg, pr, size_of)
+        node1, on1 = pr.level(1)
+        rb = bytes(root.proof)
+        assert on1.verify(rb) is None
+        pis = [int(x) for x in np.frombuffer(rb[-8 * node1.desc.num_public_inputs:], dtype="<u8")]
+        assert len(pis) == 4 * 13
+        assert pis[0:4] == [1, 1, 0, 9] and pis[13:17] == [1, 2, 0, 9] and pis[26:30] == [2, 1, 0, 9] and pis[39:43] == [2, 2, 0, 9]
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % (ROOT, ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="3")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2

@@ -242,6 +242,24 @@ def circuit_check(rc):
         raise CircuitError(rc, circuit_lib().qpc_last_error().decode())
 
 
+def proof_size_of(d):
+    """Byte length of ProofWithPublicInputs::to_bytes for circuit descriptor `d` (csrc/proof_format.h compute_layout; SURVEY.md App. B.3)."""
+    salt = 4 if d.zero_knowledge else 0
+    nch = d.num_challenges
+    S, W = d.num_constants + d.num_routed, d.num_wires
+    Zp, Q = nch * (1 + d.num_partial_products), nch * d.quotient_degree_factor
+    cap_bytes = (1 << d.fri_cap_height) * 32
+    nop = S + W + 2 * nch + nch * d.num_partial_products + Q
+    path = d.degree_bits + d.fri_rate_bits - d.fri_cap_height
+    per_query = sum(8 * w + 1 + 32 * path for w in (S, W + salt, Zp + salt, Q + salt))
+    lg = d.degree_bits
+    for layer in range(d.fri_num_layers):
+        a = d.fri_arity_bits[layer]
+        per_query += (16 << a) + 1 + 32 * (lg + d.fri_rate_bits - a - d.fri_cap_height)
+        lg -= a
+    return 3 * cap_bytes + 16 * nop + d.fri_num_layers * cap_bytes + per_query * d.fri_num_queries + 16 * (1 << lg) + 8 + 8 + 8 * d.num_public_inputs
+
+
 def hash_no_pad(felts):
     a = np.ascontiguousarray(felts, dtype=np.uint64)
     out = np.zeros(4, dtype=np.uint64)
