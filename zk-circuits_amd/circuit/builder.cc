@@ -111,6 +111,8 @@ void Builder::build() {
       hash_no_pad(buf.data(), buf.size(), acc);
     }
     memcpy(d.circuit_digest, acc, sizeof acc); }
+  // build-time indexes are not needed to generate witnesses
+  wire_ids_ = {}; arith_cache_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
   built_ = true;
 }
 

@@ -231,7 +231,7 @@ int qpc_circuit_build(uint32_t kind, uint32_t zero_knowledge, qpc_circuit** out)
 void qpc_circuit_destroy(qpc_circuit* c) { delete c; }
 const qpgpu_circuit_desc* qpc_circuit_desc(const qpc_circuit* c) { return c ? &c->b.desc() : nullptr; }
 size_t qpc_circuit_num_inputs(const qpc_circuit* c) { return c ? c->b.num_inputs() : 0; }
-void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]) { c->b.row_counts(out); out[6] = (uint32_t)c->b.num_gate_rows(); }
+void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]) { if (!c || !out) return; c->b.row_counts(out); out[6] = (uint32_t)c->b.num_gate_rows(); }
 
 int qpc_generate_witness(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs) { return guard([&]() -> int {
   if (!c || !inputs || !wires || (!public_inputs && c->b.desc().num_public_inputs)) return fail(QPGPU_ERR_ARG, "null argument");

@@ -64,6 +64,12 @@ struct Inner {                               // the circuit whose proofs are ver
     if (d.num_wires != W_ || d.num_routed != R_ || d.num_challenges != 2 || d.fri_rate_bits != 3 || d.quotient_degree_factor != 8 || d.num_gate_constraints != 123)
       return "inner circuit is not a standard_recursion_config circuit";
     if (d.fri_num_layers > 8 || d.degree_bits + d.fri_rate_bits > 28 || d.fri_cap_height > d.degree_bits) return "inner FRI shape out of range";
+    if (d.num_selector_groups < 1 || d.num_constants != d.num_selector_groups + 2 || d.num_gates < 1 || d.num_gates > 16) return "inner selector / constant columns out of range";
+    if ((d.num_partial_products + 1) * d.quotient_degree_factor < d.num_routed || d.fri_num_queries < 1 || d.fri_num_queries > 64 || d.fri_pow_bits > 32) return "inner circuit shape out of range";
+    { uint32_t lg = d.degree_bits + d.fri_rate_bits, sum = 0;
+      for (uint32_t i = 0; i < d.fri_num_layers; i++) { const uint32_t a = d.fri_arity_bits[i]; if (a < 1 || a > 4 || lg < a + d.fri_cap_height) return "inner FRI arities out of range"; lg -= a; sum += a; }
+      if (sum > d.degree_bits) return "inner FRI reductions exceed the degree"; }
+    for (uint32_t i = 0; i < d.num_gates; i++) if (src.selector_indices[i] >= d.num_selector_groups) return "inner selector index out of range";
     log_n = d.degree_bits; rate = d.fri_rate_bits; log_N = log_n + rate; cap_h = d.fri_cap_height; nch = d.num_challenges;
     S = d.num_constants + d.num_routed; W = d.num_wires; npp = d.num_partial_products; Zp = nch * (1 + npp); Q = nch * d.quotient_degree_factor;
     salt = d.zero_knowledge ? 4 : 0; nlayers = d.fri_num_layers; npi = d.num_public_inputs;
