@@ -159,6 +159,7 @@ class RecursiveChunkProver:
         self.salt_seed = salt_seed
         self._levels = {}               # (level, children per node) -> (WormholeCircuitData of the node circuit, inner circuit data, its cap, its digest)
         self._level_width = {}          # level -> children per node of the (full) chunks proved at that level
+        self._pool = {}                 # (level, children per node) -> reusable (wires, public_inputs) buffers
 
     def level(self, level, width):
         from .prover import WormholeCircuitData
@@ -182,30 +183,45 @@ class RecursiveChunkProver:
         zk = bool(cd.desc.zero_knowledge)                 # a node takes its children's config (tree.rs:111)
         blinding_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
 
-        def witness(chunk):
+        # witness matrices (35 MB each at 2^15 rows) are reused from call to call: fresh ones cost more in page faults than in arithmetic
+        pool = self._pool.setdefault((level, width), [])
+        while len(pool) < len(chunks):
+            pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
+
+        def witness(chunk, slot=0):
             raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunk]
             try:
-                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key)
+                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key, out=pool[slot])
             except ffi.CircuitError as e:
                 raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
-        if len(chunks) > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(len(chunks), max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
-                wit = list(ex.map(witness, chunks))
-        else:
-            wit = [witness(chunks[0])]
-        b = len(wit)
-        wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w, _ in wit])
-        pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
-        o = ffi.ProveOpts()
-        if zk:
-            key, o.salt_stream = (ffi.TEST_SALT_KEY, self.salt_seed + (level << 20)) if self.salt_seed is not None else (os.urandom(32), 0)
-            keep = ffi.set_salt_key(o, key)      # noqa: F841
-        buf = ctypes.create_string_buffer(cd.proof_size * b)
-        lens = (ctypes.c_size_t * b)()
-        ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf, cd.proof_size, lens))
-        return [AggregatedProof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs), cd)
-                for i in range(b)]
+        salt_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
+
+        def prove(wit, first):                               # one device batch (qpgpu_prove_batch: worker streams inside the library)
+            b = len(wit)
+            wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w, _ in wit])
+            pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
+            o = ffi.ProveOpts()
+            if zk:                                           # proof i of the level takes salt stream base + i
+                o.salt_stream = first + ((self.salt_seed + (level << 20)) if self.salt_seed is not None else 0)
+                keep = ffi.set_salt_key(o, salt_key)         # noqa: F841
+            buf = ctypes.create_string_buffer(cd.proof_size * b)
+            lens = (ctypes.c_size_t * b)()
+            ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf, cd.proof_size, lens))
+            return [AggregatedProof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs), cd)
+                    for i in range(b)]
+        if len(chunks) == 1:
+            return prove([witness(chunks[0])], 0)
+        # witnesses on host threads (generation releases the GIL), proofs in device batches of GROUP nodes: the device proves a group while
+        # the host generates the next ones
+        from concurrent.futures import ThreadPoolExecutor
+        out = []
+        with ThreadPoolExecutor(max_workers=min(len(chunks), max(2, len(os.sched_getaffinity(0)) // 2))) as ex:
+            futures = [ex.submit(witness, c, i) for i, c in enumerate(chunks)]
+            for first in range(0, len(chunks), self.GROUP):
+                out += prove([f.result() for f in futures[first:first + self.GROUP]], first)
+        return out
+
+    GROUP = 8
 
     def __call__(self, chunk, level):
         return self.prove_chunks([chunk], level)[0]
