@@ -40,10 +40,16 @@ int main(int argc, char** argv) {
     if (!verdicts[0] || verdicts[1] || !verdicts[2]) return 3;
     CircuitInputs bad = inputs; bad.pub.root_hash.fill(0);                     // storage_proof_tests.rs:29-34: commit accepts, prove fails
     try { WormholeProver(prover.circuit_data).commit(bad).prove(); return 5; } catch (const std::runtime_error& e) { std::printf("invalid root hash rejected: %.96s...\n", e.what()); }
-    WormholeProofAggregator agg(TreeAggregationConfig(2, 1));
-    agg.push_proof(proof); agg.push_proof(proof2);
-    auto leaves = agg.aggregate(proof);
-    std::printf("aggregator leaf set: %zu proofs\n", leaves.size());
+    // aggregator_tests.rs:60-112 / tree.rs:189-216: three leaves + the dummy proof, aggregated to a root whose nodes verify their children in-circuit
+    WormholeProofAggregator agg(TreeAggregationConfig(2, 2));
+    agg.push_proof(proof); agg.push_proof(proof2); agg.push_proof(proof);
+    auto t6 = std::chrono::steady_clock::now();
+    AggregatedProof root = agg.aggregate(/*dummy=*/proof, prover.circuit_data);
+    auto t7 = std::chrono::steady_clock::now();
+    WormholeVerifier(root.circuit_data).verify(root.proof);                    // root_proof.circuit_data.verify(root_proof.proof)
+    std::printf("aggregated 4 leaves -> root (2^%u rows, %zu public inputs) in %.1f ms incl. building 2 node circuits; root verified\n",
+                root.circuit_data->common().degree_bits, root.proof.public_inputs.size(), ms(t6, t7));
+    if (root.proof.public_inputs.size() != 64 || !std::equal(proof2.public_inputs.begin(), proof2.public_inputs.end(), root.proof.public_inputs.begin() + 16)) return 6;
     try { prover.commit(inputs); return 2; } catch (const std::runtime_error& e) { std::printf("second commit rejected: %s\n", e.what()); }
     // ---- the synthetic wormhole-shaped circuit (bench shape): seeded full witnesses
     WormholeProver synth = WormholeProver::create(CircuitConfig::synthetic(zk ? "B" : "A"));

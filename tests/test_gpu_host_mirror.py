@@ -163,6 +163,7 @@ def test_cpp_host_mirror_example(arg):
     assert "funding_amount 1000000000000, nullifier a94c9623" in r.stdout           # prover_tests.rs:29-43: the real circuit on the reference's inputs
     assert "invalid root hash rejected" in r.stdout and "set twice with different values" in r.stdout
     assert "synthetic shape %s" % ("B" if arg == "zk" else "A") in r.stdout
+    assert "aggregated 4 leaves -> root (2^%d rows, 64 public inputs)" % (15 if arg == "zk" else 14) in r.stdout and "root verified" in r.stdout
 
 
 def test_prove_and_verify_from_files(pkg, tmp_path):

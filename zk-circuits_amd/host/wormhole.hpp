@@ -77,6 +77,7 @@ struct WitnessInputs {                        // a full witness (synthetic circu
 
 class CircuitData {                           // ProverCircuitData: resident on the GPU, shareable between provers
  public:
+  CircuitData(const CircuitData&) = delete;
   CircuitData(const CircuitConfig& cfg, int device = 0) {
     if (!cfg.preset) {                                          // WormholeCircuit::new(config).build_prover() (lib.rs:190-202)
       if (qpc_circuit_build(QPC_WORMHOLE, cfg.zero_knowledge, &built_) != 0) throw std::runtime_error(qpc_last_error());
@@ -90,8 +91,38 @@ class CircuitData {                           // ProverCircuitData: resident on 
     if (qpgpu_ctx_create(device, &ctx_) != 0) throw std::runtime_error(qpgpu_last_error());
     if (qpgpu_circuit_create(ctx_, desc_, &circuit_) != 0) throw std::runtime_error(qpgpu_last_error());
   }
+  // The circuit of one aggregation-tree node (aggregate_chunk, tree.rs:106-128): verifies `num_proofs` proofs of `inner` in-circuit.
+  CircuitData(const CircuitData& inner, uint32_t num_proofs, int device = 0) {
+    if (qpc_aggregation_circuit_build(&inner.common(), num_proofs, &built_) != 0) throw std::runtime_error(qpc_last_error());
+    desc_ = qpc_circuit_desc(built_);
+    if (qpgpu_ctx_create(device, &ctx_) != 0) throw std::runtime_error(qpgpu_last_error());
+    if (qpgpu_circuit_create(ctx_, desc_, &circuit_) != 0) throw std::runtime_error(qpgpu_last_error());
+  }
   ~CircuitData() { if (circuit_) qpgpu_circuit_destroy(circuit_); if (ctx_) qpgpu_ctx_destroy(ctx_); if (synth_) qpsynth_circuit_destroy(synth_); if (built_) qpc_circuit_destroy(built_); }
-  CircuitData(const CircuitData&) = delete; CircuitData& operator=(const CircuitData&) = delete;
+  CircuitData& operator=(const CircuitData&) = delete;
+  std::vector<uint64_t> constants_sigmas_cap() const {
+    std::vector<uint64_t> cap((size_t)4 << desc_->fri_cap_height);
+    if (qpgpu_circuit_constants_sigmas_cap(circuit_, cap.data()) != 0) throw std::runtime_error(qpgpu_last_error());
+    return cap;
+  }
+  // set_verifier_data_target + set_proof_with_pis_target + generate_partial_witness for a node circuit: the children's proofs (of `inner`) ->
+  // the node's witness. A child that does not verify throws.
+  WitnessInputs aggregation_witness(const CircuitData& inner, const std::vector<ProofWithPublicInputs>& children) const {
+    if (!built_) throw std::runtime_error("not an aggregation node circuit");
+    if (children.empty()) throw std::runtime_error("no child proofs");
+    const size_t len = children[0].bytes.size(); std::vector<uint8_t> flat(len * children.size());
+    for (size_t i = 0; i < children.size(); i++) { if (children[i].bytes.size() != len) throw std::runtime_error("children of one node have one size"); memcpy(&flat[i * len], children[i].bytes.data(), len); }
+    const std::vector<uint64_t> cap = inner.constants_sigmas_cap();
+    std::vector<uint64_t> targets(qpc_circuit_num_inputs(built_)); size_t n_t = 0;
+    if (qpc_aggregation_fill_targets(built_, cap.data(), inner.common().circuit_digest, flat.data(), len, len, (uint32_t)children.size(), targets.data(), targets.size(), &n_t) != 0)
+      throw std::runtime_error(qpc_last_error());
+    WitnessInputs w; const size_t n = size_t(1) << desc_->degree_bits;
+    w.wires.resize((size_t)desc_->num_wires * n); w.public_inputs.resize(desc_->num_public_inputs);
+    const auto blinding = WitnessInputs::random_salt_key();
+    if (qpc_generate_witness(built_, targets.data(), n_t, blinding.data(), w.wires.data(), w.public_inputs.data()) != 0)
+      throw std::runtime_error(std::string("a child proof of this node does not verify: ") + qpc_last_error());
+    return w;
+  }
   const qpgpu_circuit_desc& common() const { return *desc_; }
   qpgpu_circuit* handle() const { return circuit_; }
   qpgpu_ctx* context() const { return ctx_; }
@@ -205,7 +236,31 @@ struct TreeAggregationConfig {                 // circuits/tree.rs:32-55
   TreeAggregationConfig(size_t b, uint32_t d) : tree_branching_factor(b), tree_depth(d), num_leaf_proofs(1) { for (uint32_t i = 0; i < d; i++) num_leaf_proofs *= b; }
 };
 
-class WormholeProofAggregator {                // aggregator.rs:13-92 (buffering + padding; the recursion circuit is "next")
+struct AggregatedProof { ProofWithPublicInputs proof; std::shared_ptr<CircuitData> circuit_data; };     // tree.rs:24-28
+
+// aggregate_to_tree / aggregate_level / aggregate_chunk (tree.rs:56-143): level by level, consecutive chunks of `tree_branching_factor`
+// children, one node proof each. The node circuit of a level is built once (the reference rebuilds it per chunk, tree.rs:112-128).
+
+inline AggregatedProof aggregate_to_tree(std::vector<ProofWithPublicInputs> proofs, std::shared_ptr<CircuitData> inner, const TreeAggregationConfig& config) {
+  if (proofs.empty()) throw std::runtime_error("there are no proofs to aggregate");
+  std::shared_ptr<CircuitData> node;
+  do {
+    const size_t b = config.tree_branching_factor;
+    std::vector<ProofWithPublicInputs> parents;
+    std::shared_ptr<CircuitData> full;                                        // the level's circuit for full chunks
+    for (size_t i = 0; i < proofs.size(); i += b) {
+      std::vector<ProofWithPublicInputs> chunk(proofs.begin() + i, proofs.begin() + std::min(proofs.size(), i + b));
+      if (chunk.size() == b) { if (!full) full = std::make_shared<CircuitData>(*inner, (uint32_t)b); node = full; }
+      else node = std::make_shared<CircuitData>(*inner, (uint32_t)chunk.size());   // a ragged last chunk: its own, narrower circuit
+      WormholeProver prover(node);
+      parents.push_back(prover.commit(node->aggregation_witness(*inner, chunk)).prove());
+    }
+    proofs = std::move(parents); inner = node;
+  } while (proofs.size() > 1);
+  return AggregatedProof{std::move(proofs[0]), node};
+}
+
+class WormholeProofAggregator {                // aggregator.rs:13-92
  public:
   explicit WormholeProofAggregator(TreeAggregationConfig cfg = {}) : config(cfg), proofs_buffer(std::vector<ProofWithPublicInputs>()) {}
   void push_proof(ProofWithPublicInputs p) {
@@ -214,13 +269,17 @@ class WormholeProofAggregator {                // aggregator.rs:13-92 (buffering
       proofs_buffer->push_back(std::move(p));
     } else proofs_buffer = std::vector<ProofWithPublicInputs>{std::move(p)};
   }
-  // Returns the padded leaf set the aggregator step consumes (util.rs:11-29 padding rule).
-  std::vector<ProofWithPublicInputs> aggregate(const ProofWithPublicInputs& dummy) {
+  // The padded leaf set the aggregator step consumes (util.rs:11-29 padding rule).
+  std::vector<ProofWithPublicInputs> padded_leaves(const ProofWithPublicInputs& dummy) {
     if (!proofs_buffer) throw std::runtime_error("there are no proofs to aggregate");
     auto proofs = std::move(*proofs_buffer); proofs_buffer.reset();
     if (proofs.size() > config.num_leaf_proofs) throw std::runtime_error("proofs to aggregate was more than the maximum allowed");
     while (proofs.size() < config.num_leaf_proofs) proofs.push_back(dummy);
     return proofs;
+  }
+  // aggregator.rs:74-92: pad with the dummy proof and aggregate to the root proof of the tree.
+  AggregatedProof aggregate(const ProofWithPublicInputs& dummy, std::shared_ptr<CircuitData> leaf_circuit_data) {
+    return aggregate_to_tree(padded_leaves(dummy), std::move(leaf_circuit_data), config);
   }
   TreeAggregationConfig config;
   std::optional<std::vector<ProofWithPublicInputs>> proofs_buffer;
