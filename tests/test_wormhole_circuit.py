@@ -210,3 +210,75 @@ def test_vote_circuit(circuits):
                                pkg.VotePrivateInputs(keys[19], sib, path, 5))
     w, p = c.witness(deep.fill_targets())
     assert check_witness(oc, w, p) is None and int(p[8]) == 0
+
+
+def _random_storage_inputs(rng, num_nodes):
+    """A valid CircuitInputs with a made-up storage proof of `num_nodes` nodes: node i embeds H(node i+1) (four little-endian u64) at a
+    felt-aligned offset, node 0 hashes to the root, the last node embeds a digest whose limbs 1..3 are those of the leaf-inputs hash — the
+    statement storage_proof/mod.rs:140-244 checks, with other lengths, offsets and node sizes than the one fixture of the reference."""
+    ffi = pkg.ffi
+    secret = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    tc = int(rng.integers(0, 1 << 40))
+    amount = int(rng.integers(0, 1 << 62)) << int(rng.integers(0, 60))
+    funding = pkg.BytesDigest(b"".join(int(rng.integers(0, P, dtype=np.uint64)).to_bytes(8, "little") for _ in range(4)))
+    unspendable = pkg.unspendable_account_from_secret(secret)
+    leaf_felts = [tc >> 32, tc & 0xFFFFFFFF] + funding.to_felts() + unspendable.to_felts() + [(amount >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)]
+    leaf_hash = [int(v) for v in ffi.hash_no_pad(leaf_felts)]
+    embedded = [int(rng.integers(0, P, dtype=np.uint64))] + leaf_hash[1:]                       # limb 0 is not compared (storage_proof/mod.rs:232-240)
+    nodes, indices = [], []
+    for i in reversed(range(num_nodes)):
+        size = int(rng.integers(10, 189)) * 4                                    # 10..188 felts
+        off = int(rng.integers(0, min(size // 4 - 8, 179) + 1)) * 4              # felt-aligned, 8 felts fit, felt index <= 179
+        body = bytearray(rng.integers(0, 256, size, dtype=np.uint8))
+        body[off:off + 32] = b"".join(v.to_bytes(8, "little") for v in embedded)
+        nodes.insert(0, bytes(body)); indices.insert(0, off * 2)                 # hex-digit index
+        felts = [int.from_bytes(body[k:k + 4], "little") for k in range(0, size, 4)]
+        embedded = [int(v) for v in ffi.hash_no_pad(felts + [0] * (188 - len(felts)))]
+    root = pkg.BytesDigest(b"".join(v.to_bytes(8, "little") for v in embedded))
+    exit_account = pkg.BytesDigest(b"".join(int(rng.integers(0, P, dtype=np.uint64)).to_bytes(8, "little") for _ in range(4)))
+    return pkg.CircuitInputs(pkg.PublicCircuitInputs(amount, pkg.nullifier_from_preimage(secret, tc), root, exit_account),
+                             pkg.PrivateCircuitInputs(secret, pkg.ProcessedStorageProof(nodes, indices), tc, funding, unspendable))
+
+
+@pytest.mark.parametrize("num_nodes", [1, 2, 7, 13, 19, 20])
+def test_wormhole_circuit_accepts_other_valid_inputs(circuits, num_nodes):
+    """The one fixture of the reference exercises one proof length and one set of offsets; these are made-up valid statements of every
+    shape the circuit allows (1..20 nodes, nodes of 10..188 felts, child hash at any felt offset 0..179)."""
+    c, oc = circuits(QPC_WORMHOLE)
+    rng = np.random.default_rng(1000 + num_nodes)
+    ci = _random_storage_inputs(rng, num_nodes)
+    w, p = c.witness(ci.fill_targets())
+    assert check_witness(oc, w, p) is None
+    pub = pkg.PublicCircuitInputs.try_from_slice(p)
+    assert pub == ci.public
+    # and the same statement stops holding when any one of its parts moves
+    bad = copy.deepcopy(ci); bad.private.transfer_count ^= 1; bad.public.nullifier = pkg.nullifier_from_preimage(bad.private.secret, bad.private.transfer_count)
+    if num_nodes < 20:                                                            # with 20 nodes the leaf check has no iteration left (i == proof_len never happens): upstream's loop, mirrored
+        _fails(c, bad, QPC_WORMHOLE)
+    else:
+        c.witness(bad.fill_targets())
+    bad = copy.deepcopy(ci); sp = bad.private.storage_proof
+    k = int(rng.integers(num_nodes)); b = bytearray(sp.proof[k]); b[int(rng.integers(len(b)))] ^= 0x10; sp.proof[k] = bytes(b)
+    _fails(c, bad, QPC_WORMHOLE)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 17, 32])
+def test_vote_circuit_accepts_any_depth(circuits, depth):
+    """Merkle membership along a made-up path of `depth` levels (0 = the root is the voter's leaf; 32 = MAX_MERKLE_DEPTH, voting/src/lib.rs:20)."""
+    c, oc = circuits(QPC_VOTE)
+    rng = np.random.default_rng(50 + depth)
+    h = pkg.ffi.hash_no_pad
+    key = [int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)]
+    sib = [[int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)] for _ in range(depth)]
+    path = [bool(v) for v in rng.integers(0, 2, depth)]
+    leaf = [int(v) for v in h(key)]; cur = leaf
+    for s_, right in zip(sib, path):
+        cur = [int(v) for v in h((s_ + cur) if right else (cur + s_))]
+    prop = [int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)]
+    data = pkg.VoteCircuitData(pkg.VotePublicInputs(prop, cur, bool(depth & 1), [int(v) for v in h(leaf + prop)]), pkg.VotePrivateInputs(key, sib, path, depth))
+    w, p = c.witness(data.fill_targets())
+    assert check_witness(oc, w, p) is None and list(p) == prop + cur + [depth & 1] + data.public_inputs.nullifier
+    if depth:
+        bad = copy.deepcopy(data); bad.private_inputs.path_indices[depth // 2] ^= True
+        with pytest.raises(CircuitError, match="set twice with different values"):
+            c.witness(bad.fill_targets())
