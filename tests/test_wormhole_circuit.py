@@ -262,9 +262,11 @@ def test_wormhole_circuit_accepts_other_valid_inputs(circuits, num_nodes):
     _fails(c, bad, QPC_WORMHOLE)
 
 
-@pytest.mark.parametrize("depth", [0, 1, 17, 32])
+@pytest.mark.parametrize("depth", [0, 1, 17, 31, 32])
 def test_vote_circuit_accepts_any_depth(circuits, depth):
-    """Merkle membership along a made-up path of `depth` levels (0 = the root is the voter's leaf; 32 = MAX_MERKLE_DEPTH, voting/src/lib.rs:20)."""
+    """Merkle membership along a made-up path of `depth` levels (0 = the root is the voter's leaf). MAX_MERKLE_DEPTH is 32 (voting/src/lib.rs:20)
+    and fill_targets admits it, but the circuit compares the depth over n_log = bits(MAX - 1) = 5 bits (lib.rs:131-134), so depth 32 cannot be
+    witnessed: upstream's behaviour, mirrored (31 is the deepest provable path)."""
     c, oc = circuits(QPC_VOTE)
     rng = np.random.default_rng(50 + depth)
     h = pkg.ffi.hash_no_pad
@@ -276,6 +278,10 @@ def test_vote_circuit_accepts_any_depth(circuits, depth):
         cur = [int(v) for v in h((s_ + cur) if right else (cur + s_))]
     prop = [int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)]
     data = pkg.VoteCircuitData(pkg.VotePublicInputs(prop, cur, bool(depth & 1), [int(v) for v in h(leaf + prop)]), pkg.VotePrivateInputs(key, sib, path, depth))
+    if depth == 32:
+        with pytest.raises(CircuitError, match="set twice with different values"):
+            c.witness(data.fill_targets())
+        return
     w, p = c.witness(data.fill_targets())
     assert check_witness(oc, w, p) is None and list(p) == prop + cur + [depth & 1] + data.public_inputs.nullifier
     if depth:
