@@ -361,6 +361,8 @@ def main():
                     torch.cuda.synchronize(); tb = (time.perf_counter() - ta) / reps_
                     matrix.append({"branching": b_, "depth": d_, "leaves": cfg_.num_leaf_proofs, "nodes": sum(b_ ** k for k in range(d_)),
                                    "node_degree_bits": int(r_.circuit_data.desc.degree_bits), "aggregate_ms": round(tb * 1e3, 3)})
+                    if pr_ is not np_:
+                        pr_.close()                                                    # wider node circuits are used once: free their device memory
                 tree["bench_matrix"] = matrix
             # the aggregator's intake check: all 64 leaf proofs through the product's batch verifier (device Merkle openings + host algebra)
             try:

@@ -226,6 +226,12 @@ class RecursiveChunkProver:
     def __call__(self, chunk, level):
         return self.prove_chunks([chunk], level)[0]
 
+    def close(self):
+        """Frees the node circuits' device memory and the witness buffers (proofs already returned stay valid; their circuit_data does not)."""
+        for cd, _, _, _ in self._levels.values():
+            cd.close()
+        self._levels, self._pool = {}, {}
+
     def proof_size_of_level(self, level, width=DEFAULT_TREE_BRANCHING_FACTOR):
         """Byte size of the proofs that ENTER `level` (aggregate_to_tree_distributed's exchange size)."""
         return self.leaf.proof_size if level == 0 else self.level(level - 1, width)[0].proof_size

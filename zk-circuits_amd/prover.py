@@ -142,6 +142,20 @@ class WormholeCircuitData:
         self.proof_size = L.qpgpu_proof_size(self._circuit)
         return self
 
+    def close(self):
+        """Frees the device-resident circuit (qpgpu_circuit_destroy / qpgpu_ctx_destroy); the object is unusable afterwards."""
+        L = ffi.lib()
+        if getattr(self, "_circuit", None):
+            L.qpgpu_circuit_destroy(self._circuit); self._circuit = None
+        if getattr(self, "_ctx", None):
+            L.qpgpu_ctx_destroy(self._ctx); self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def common_bytes(self):
         return ffi.write_common(self.desc)
 
