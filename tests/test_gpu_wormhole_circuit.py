@@ -161,3 +161,13 @@ def test_recursive_aggregation_of_zk_leaves():
     root = prover([node.proof, again.proof], 1)                                 # a zk node verifies zk nodes
     assert root.circuit_data.desc.degree_bits == 15 and len(root.proof.public_inputs) == 64
     pkg.WormholeVerifier.new(None, circuit_data=root.circuit_data).verify(root.proof)
+
+
+def test_the_reference_example(tmp_path):
+    """examples/wormhole_example.py = wormhole/example/src/main.rs:13-74 (hand-built inputs with an empty storage proof)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wormhole_example", os.path.join(ROOT, "examples", "wormhole_example.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    proof, pub = mod.main(str(tmp_path / "proof.hex"))
+    assert pub.funding_amount == 10 ** 12 and bytes(pub.exit_account[:8]) == (8226349481601990196).to_bytes(8, "little")
+    assert bytes.fromhex(open(tmp_path / "proof.hex").read()) == proof.to_bytes() and len(proof) == 132712

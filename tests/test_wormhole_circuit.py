@@ -288,3 +288,23 @@ def test_vote_circuit_accepts_any_depth(circuits, depth):
         bad = copy.deepcopy(data); bad.private_inputs.path_indices[depth // 2] ^= True
         with pytest.raises(CircuitError, match="set twice with different values"):
             c.witness(bad.fill_targets())
+
+
+def test_the_reference_example_inputs_with_an_empty_storage_proof(circuits):
+    """wormhole/example/src/main.rs:13-74: no storage-proof nodes, the root hash is the leaf-inputs hash itself (the leaf check fires at
+    i = 0 = proof_len), secret [1; 32], transfer count 0, exit account id 8226349481601990196."""
+    c, oc = circuits(QPC_WORMHOLE)
+    secret = bytes([1] * 32)
+    funding = pkg.BytesDigest(th.DEFAULT_FUNDING_ACCOUNT)                         # "Alice's dev account": the same bytes as the test helpers'
+    unspendable = pkg.unspendable_account_from_secret(secret)
+    amount = 1_000_000_000_000
+    leaf_felts = [0, 0] + funding.to_felts() + unspendable.to_felts() + [(amount >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)]
+    root = pkg.BytesDigest.from_felts([int(v) for v in pkg.ffi.hash_no_pad(leaf_felts)])
+    exit_account = pkg.BytesDigest((8226349481601990196).to_bytes(8, "little") + bytes(24))
+    ci = pkg.CircuitInputs(pkg.PublicCircuitInputs(amount, pkg.nullifier_from_preimage(secret, 0), root, exit_account),
+                           pkg.PrivateCircuitInputs(secret, pkg.ProcessedStorageProof([], []), 0, funding, unspendable))
+    w, p = c.witness(ci.fill_targets())
+    assert check_witness(oc, w, p) is None
+    assert pkg.PublicCircuitInputs.try_from_slice(p) == ci.public
+    bad = copy.deepcopy(ci); bad.public.funding_amount += 1                       # another amount: the leaf-inputs hash no longer matches the root
+    _fails(c, bad, QPC_WORMHOLE)
