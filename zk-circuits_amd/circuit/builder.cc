@@ -26,8 +26,11 @@ const uint64_t PARAM[K_KINDS] = {0, 2, 0, BASESUM_LIMBS, ARITH_OPS, 0};
 const uint32_t NUM_QUERIES = 28, CAP_HEIGHT = 4, POW_BITS = 16, RATE_BITS = 3;
 }
 
+static double now_ms();
 void Builder::build() {
   if (built_) return;
+  static const bool tmb = getenv("QPC_TIMING") != nullptr; double tb0 = now_ms();
+  auto lapb = [&](const char* what) { if (tmb) { double t = now_ms(); fprintf(stderr, "  build %-10s %.3f ms\n", what, t - tb0); tb0 = t; } };
   // public inputs: hashed in-circuit, the digest tied to the PublicInput gate's wires (plonky2 does the same in build()).
   { Hash4 h = hash_n_to_hash_no_pad(public_inputs_); for (int i = 0; i < 4; i++) connect(h.e[i], wire(0, i)); }
   gate_rows_ = row_kind_.size();
@@ -49,6 +52,7 @@ void Builder::build() {
   n_ = size_t(1) << k;
   row_kind_.resize(n_, K_NOOP); row_c0_.resize(n_, 0); row_c1_.resize(n_, 0);
 
+  lapb("rows");
   // copy classes
   cls_.resize(cells_.size());
   { std::vector<uint32_t> index(cells_.size(), UINT32_MAX); ncls_ = 0;
@@ -62,13 +66,20 @@ void Builder::build() {
   // sigma: the routed cells of a class form one cycle; a blinding pair swaps its two cells
   std::vector<uint32_t> sigma((size_t)R * n_);
   for (size_t i = 0; i < sigma.size(); i++) sigma[i] = (uint32_t)i;
-  { std::vector<std::vector<uint32_t>> members(ncls_);
-    for (Target t : wire_targets_) if (cells_[t].col < R) members[cls_[t]].push_back((uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row));
-    for (auto& m : members) for (size_t i = 0; i + 1 <= m.size() && m.size() > 1; i++) sigma[m[i]] = m[(i + 1) % m.size()]; }
+  { std::vector<uint32_t> start(ncls_ + 1, 0);                         // routed cells grouped by class (counting sort), each group one cycle
+    for (Target t : wire_targets_) if (cells_[t].col < R) start[cls_[t] + 1]++;
+    for (size_t c = 0; c < ncls_; c++) start[c + 1] += start[c];
+    std::vector<uint32_t> cellv(start[ncls_]), fillp(start.begin(), start.end() - 1);
+    for (Target t : wire_targets_) if (cells_[t].col < R) cellv[fillp[cls_[t]]++] = (uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row);
+    for (size_t c = 0; c < ncls_; c++) {
+      const uint32_t lo = start[c], hi = start[c + 1];
+      if (hi - lo > 1) for (uint32_t i = lo; i < hi; i++) sigma[cellv[i]] = cellv[i + 1 < hi ? i + 1 : lo];
+    } }
   for (size_t p = 0; p < blind_pairs_; p++) for (int c = 0; c < R; c++) {
     const size_t a = (size_t)c * n_ + blind_pair_first_ + 2 * p, b = a + 1; sigma[a] = (uint32_t)b; sigma[b] = (uint32_t)a;
   }
 
+  lapb("sigma");
   // gate list ordered by degree; selector groups as upstream forms them (a group grows while size + next degree < 8): [0,5), [5,6)
   int gate_index[K_KINDS];
   { std::vector<int> kinds; for (int i = 0; i < K_KINDS; i++) kinds.push_back(i);
@@ -95,6 +106,7 @@ void Builder::build() {
     for (size_t i = 0; i < n_; i++) { wpow[i] = x; x = gl_mul(x, w); }
     for (int j = 0; j < R; j++) for (size_t i = 0; i < n_; i++) { uint32_t t = sigma[(size_t)j * n_ + i]; cs[(size_t)(nsel + 2 + j) * n_ + i] = gl_mul(k_is_[t / n_], wpow[t % n_]); } }
 
+  lapb("columns");
   qpgpu_circuit_desc& d = desc_; memset(&d, 0, sizeof d);
   d.degree_bits = k; d.num_wires = W; d.num_routed = R; d.num_constants = (uint32_t)(nsel + 2); d.num_challenges = 2;
   d.quotient_degree_factor = 8; d.num_partial_products = 9; d.num_public_inputs = (uint32_t)public_inputs_.size(); d.num_gate_constraints = 123;
@@ -104,16 +116,23 @@ void Builder::build() {
   d.selector_group_ranges = groups_.data(); d.k_is = k_is_.data(); d.constants_sigmas = cs;
   // Circuit digest: binds every constants/sigmas value and the shape (upstream hashes the constants/sigmas cap with the common data;
   // any four felts that commit to the circuit serve the transcript — this one is this builder's own).
-  { u64 acc[4] = {k, (u64)zk_, (u64)public_inputs_.size(), (u64)gate_rows_};
-    std::vector<u64> buf(4 + n_);
-    for (int col = 0; col < nsel + 2 + R; col++) {
-      memcpy(buf.data(), acc, sizeof acc); memcpy(buf.data() + 4, cs + (size_t)col * n_, n_ * sizeof(u64));
-      hash_no_pad(buf.data(), buf.size(), acc);
-    }
+  { const int ncol = nsel + 2 + R;                               // one digest per column (independent sponges, spread over host threads), then one over them
+    std::vector<u64> col_digest((size_t)4 * ncol);
+    auto hash_cols = [&](int lo, int hi) { for (int col = lo; col < hi; col++) hash_no_pad(cs + (size_t)col * n_, n_, &col_digest[4 * (size_t)col]); };
+    const int nthr = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; t++) pool.emplace_back(hash_cols, ncol * t / nthr, ncol * (t + 1) / nthr);
+    hash_cols(0, ncol / nthr);
+    for (auto& th : pool) th.join();
+    std::vector<u64> buf{k, (u64)zk_, (u64)public_inputs_.size(), (u64)gate_rows_};
+    buf.insert(buf.end(), col_digest.begin(), col_digest.end());
+    u64 acc[4]; hash_no_pad(buf.data(), buf.size(), acc);
     memcpy(d.circuit_digest, acc, sizeof acc); }
+  lapb("digest");
   // build-time indexes are not needed to generate witnesses
   wire_ids_ = {}; arith_cache_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
   built_ = true;
+  lapb("free");
 }
 
 // Eight ChaCha8 blocks of csrc/salt.h's stream at once (GCC vector extensions; the same keystream as salt_block, block by block).
