@@ -1,8 +1,9 @@
 /* qpsynth — synthetic "wormhole-shaped" / "voting-shaped" circuit + witness generator (host only, no GPU).
  *
- * Stands in for the two host-side pieces of the reference that need the Rust toolchain (absent here):
- * the CircuitBuilder output of WormholeCircuit::new (/root/reference/wormhole/circuit/src/circuit.rs:76-108)
- * and qp-plonky2's generate_partial_witness behind WormholeProver::commit (wormhole/prover/src/lib.rs:209-225).
+ * Seeded circuits and witnesses of the shapes the reference's artefacts pin (wormhole/bench-data/common.bin: k = 14 zk, 135 wires, 84
+ * constants/sigmas columns, 16 public inputs; aggregator/data/dummy_proof.bin: k = 13) with random gate contents: the workloads of bench.py
+ * and of the kernel/prover parity tests, including shapes the real circuits do not reach (2^20 rows, upstream's recursion gates). The
+ * reference's actual circuits and their witness generation are include/qpcircuit.h.
  * Gate mix follows SURVEY.md §8(d) (from wormhole/circuit/src/storage_proof/mod.rs:169-243, nullifier.rs:230-238,
  * unspendable_account.rs:194-204). It is an input generator for tests and bench.py, not part of the drop-in ABI.
  */
