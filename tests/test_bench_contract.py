@@ -1,16 +1,17 @@
 """The one JSON line bench.py prints must keep the driver's contract. Checked on the committed line of the last GPU run
-(profiles/r02_bench_B.json, written by `python bench.py` on MI355X) — no GPU needed — and on bench.py's source for the parts a saved line
+(profiles/r02_bench_W.json, written by `python bench.py` on MI355X: the default workload, preset W) — no GPU needed — and on bench.py's source for the parts a saved line
 cannot show (single JSON line on stdout, defaults, barrier + max over ranks)."""
 import json, os, re
 from harness import ROOT
 
 
 def test_saved_bench_line_has_the_contract_fields():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_B.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_W.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["metric"] == "wormhole proofs/s" and d["unit"] == "proofs/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"].startswith("u64") and d["n_gpus"] == 1
+    assert d["vs_baseline"] is None and d["data"].startswith("synthetic") and d["dtype"].startswith("u64") and d["n_gpus"] == 1
+    assert d["config"]["preset"] == "W" and "wormhole-circuit proof" in d["config"]["workload"]         # the default workload is the wormhole circuit itself
     assert "workload" in d["config"] and "model" not in d["config"] and "configs[1]" in d["config"]["workload"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-3                      # one proof per step at N = 1
     r = d["roofline"]
@@ -25,11 +26,11 @@ def test_saved_bench_line_has_the_contract_fields():
 
 
 def test_rocprof_summary_agrees_with_the_live_measurement():
-    """profiles/r02_B_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same workload) and the HIP-event average inside bench.py must
+    """profiles/r02_W_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same workload) and the HIP-event average inside bench.py must
     tell the same launch duration for the dominant kernel."""
     import csv
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_B.json")).read().strip().splitlines()[-1])
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_B_kernel_stats.csv"))))
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_W.json")).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_W_kernel_stats.csv"))))
     leaf = [r for r in rows if "k_leaves_colmajor" in r["Name"]]
     assert len(leaf) == 1
     prof_ms = float(leaf[0]["AverageNs"]) / 1e6

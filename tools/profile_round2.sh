@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-config rocprofv3 summaries (run on the GPU box from the repo root: bash tools/profile_round2.sh). One config per profiler run, extras
 # off (--no-tree --no-pipelined --no-cpu-baseline), so that every kernel_stats.csv describes exactly one workload:
-#   B  = BASELINE configs[1] (single zk leaf proof 2^14)     A = non-zk leaf 2^13      V = configs[4] (2^20 rows)      B64 = configs[2] (batch of 64)
+#   W  = BASELINE configs[1] (single proof of the wormhole circuit, zk, 2^14; the default)   B  = the same shape, synthetic gate contents     A = non-zk leaf 2^13      V = configs[4] (2^20 rows)      B64 = configs[2] (batch of 64)
 # Outputs under gpurun_out/r02prof/: <cfg>_kernel_stats.csv, <cfg>_bench.json, timeline_B.txt; copy what is to be judged into profiles/.
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -15,6 +15,8 @@ run() {   # name, bench args...
   cp $(find /tmp/pf_$name -name "${name}_kernel_stats.csv" | head -1) $OUT/${name}_kernel_stats.csv
   echo "profiled $name"
 }
+run W --preset W --steps 20 --warmup 3
+python3 $R/tools/trace_timeline.py $(find /tmp/pf_W -name "W_kernel_trace.csv" | head -1) > $OUT/timeline_W.txt
 run B --preset B --steps 20 --warmup 3
 python3 $R/tools/trace_timeline.py $(find /tmp/pf_B -name "B_kernel_trace.csv" | head -1) > $OUT/timeline_B.txt
 run A --preset A --steps 20 --warmup 3
