@@ -340,8 +340,9 @@ def main():
                 for lvl in range(depth):
                     warm = [np_([warm[0], warm[-1]], lvl).proof.to_bytes()] * 2
                 t_build = time.perf_counter() - t_build
-                if dist is None:                                  # one untimed full-width tree: per-stream workspaces of the node circuits
-                    agg.aggregate_to_tree(gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True), cfg, np_)
+                # one untimed full-width tree over this rank's leaves: per-stream workspaces of the node circuits
+                agg.aggregate_to_tree(gc.prove_batch(ptrs, pl, salt_seed=seeds[0], wires_on_device=True),
+                                      agg.TreeAggregationConfig(2, int(round(np.log2(leaves_per_rank)))), np_)
             except Exception:
                 setup_ok = 0
             if dist is not None:                                  # all ranks enter the collectives below, or none does
