@@ -171,3 +171,19 @@ def test_the_reference_example(tmp_path):
     proof, pub = mod.main(str(tmp_path / "proof.hex"))
     assert pub.funding_amount == 10 ** 12 and bytes(pub.exit_account[:8]) == (8226349481601990196).to_bytes(8, "little")
     assert bytes.fromhex(open(tmp_path / "proof.hex").read()) == proof.to_bytes() and len(proof) == 132712
+
+
+def test_aggregator_default_constructor_aggregates_to_a_root():
+    """aggregator_tests.rs:60-112 with the reference's constructors: WormholeProofAggregator::default() (zk config, tree 2^3), push leaf proofs,
+    aggregate() -> AggregatedProof whose public inputs parse back into the leaves' (extract_leaf_public_inputs) and whose proof verifies."""
+    aggregator = pkg.WormholeProofAggregator.default().with_config(pkg.TreeAggregationConfig(2, 2))
+    prover_cd = aggregator.leaf_circuit_data
+    inputs = th.circuit_test_inputs()
+    for _ in range(3):
+        aggregator.push_proof(pkg.WormholeProver(prover_cd).commit(inputs).prove())
+    aggregated = aggregator.aggregate()                                                     # pads with the circuit's dummy proof
+    leaves = aggregator.extract_leaf_public_inputs(aggregated.proof)
+    assert len(leaves) == 4 and all(_expected(x) for x in leaves)
+    pkg.WormholeVerifier.new(None, circuit_data=aggregated.circuit_data).verify(aggregated.proof)
+    with pytest.raises(RuntimeError, match="no proofs to aggregate"):
+        aggregator.aggregate()

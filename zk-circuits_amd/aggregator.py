@@ -36,10 +36,32 @@ class AggregatedLeaves:
 
 
 class WormholeProofAggregator:
-    def __init__(self, leaf_circuit_data, config=None):
+    def __init__(self, leaf_circuit_data, config=None, chunk_prover=None):
+        """aggregator.rs:28-37. `chunk_prover`: what aggregates a chunk of children into their parent (aggregate_chunk); with none set,
+        aggregate() stops at the padded leaf set. default() / from_circuit_config() attach the device prover with real recursion."""
         self.leaf_circuit_data = leaf_circuit_data
         self.config = config or TreeAggregationConfig()
         self.proofs_buffer = []
+        self.chunk_prover = chunk_prover
+
+    @staticmethod
+    def from_circuit_config(circuit_config, device=0):
+        """aggregator.rs:39-44: the leaf circuit's data compiled from the config; aggregate() then returns the root proof of the tree
+        (every node verifies its children in-circuit, RecursiveChunkProver)."""
+        from .prover import WormholeCircuitData
+        cd = WormholeCircuitData.get(circuit_config, device)
+        return WormholeProofAggregator(cd, None, RecursiveChunkProver(cd, device))
+
+    @staticmethod
+    def default(device=0):
+        """aggregator.rs:19-24: standard_recursion_zk_config."""
+        from .prover import CircuitConfig
+        return WormholeProofAggregator.from_circuit_config(CircuitConfig.standard_recursion_zk_config(), device)
+
+    def extract_leaf_public_inputs(self, aggr):
+        """aggregator.rs:64-71: the leaves' PublicCircuitInputs from an aggregated (root) proof."""
+        from .inputs import PublicCircuitInputs
+        return PublicCircuitInputs.try_from_aggregated(aggr, self.leaf_circuit_data.num_public_inputs, self.config.num_leaf_proofs)
 
     def with_config(self, config):
         self.config = config
@@ -103,6 +125,7 @@ class WormholeProofAggregator:
             if proofs and len(dummy_proof) != len(proofs[0]):
                 raise RuntimeError("failed to deserialize dummy proof: %d bytes, leaf proofs have %d" % (len(dummy_proof), len(proofs[0])))
             proofs = proofs + [dummy_proof] * (self.config.num_leaf_proofs - num_real)
+        chunk_prover = chunk_prover or self.chunk_prover
         if chunk_prover is not None:
             return aggregate_to_tree(proofs, self.config, chunk_prover)
         return AggregatedLeaves(proofs, num_real)
