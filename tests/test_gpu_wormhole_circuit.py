@@ -187,3 +187,20 @@ def test_aggregator_default_constructor_aggregates_to_a_root():
     pkg.WormholeVerifier.new(None, circuit_data=aggregated.circuit_data).verify(aggregated.proof)
     with pytest.raises(RuntimeError, match="no proofs to aggregate"):
         aggregator.aggregate()
+
+
+@pytest.mark.parametrize("kind", [QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_VOTE])
+@pytest.mark.parametrize("zk", [False, True])
+def test_every_built_circuit_proves_byte_equal_to_the_oracle(kind, zk):
+    """The fragment circuits the reference's fragment tests build alone (2^5 rows without zero knowledge: no FRI reduction at all; 2^14 with
+    its blinding rows; no public inputs for the unspendable-account fragment) and the vote circuit (2^8), through the device prover."""
+    c = BuiltCircuit(kind, zk)
+    x = th.vote_test_inputs().fill_targets() if kind == QPC_VOTE else th.circuit_test_inputs().fill_targets(kind)
+    w, p = c.witness(x, bytes(range(32)))
+    oc, gc = OracleCircuit(c.desc), GpuCircuit(c.desc)
+    salts = SynthCircuit("B").salts_keyed(TEST_SALT_KEY, 3) if zk else None
+    got = gc.prove(w, p, salt_seed=3)
+    assert got == oc.prove(w, p, salts=salts) and oc.verify(got) is None
+    v = GpuVerifier(c.desc, gc.cap())
+    assert v.verify(got) is None
+    v.close(); gc.close()
