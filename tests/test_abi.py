@@ -29,7 +29,8 @@ def test_circuit_library_exports_exactly_its_header():
     so = os.path.join(PKG, "libqpcircuit.so")
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
     exported = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and not l.split()[2].startswith("_Z")}
-    declared = set(declared_symbols("qpcircuit.h"))
+    declared = set(declared_symbols("qpcircuit.h")) | set(declared_symbols("qpcircuit_internal.h"))
+    assert set(declared_symbols("qpcircuit_internal.h")) - set(declared_symbols("qpcircuit.h")) == {"qpc_test_random_circuit"}
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     assert {"qpc_circuit_build", "qpc_generate_witness", "qpw_fill_targets", "qpv_fill_targets"} <= declared
     ldd = subprocess.run(["ldd", so], capture_output=True, text=True).stdout

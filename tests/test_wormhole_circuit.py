@@ -308,3 +308,26 @@ def test_the_reference_example_inputs_with_an_empty_storage_proof(circuits):
     assert pkg.PublicCircuitInputs.try_from_slice(p) == ci.public
     bad = copy.deepcopy(ci); bad.public.funding_amount += 1                       # another amount: the leaf-inputs hash no longer matches the root
     _fails(c, bad, QPC_WORMHOLE)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_builder_fuzz_random_programs(seed):
+    """Random programs of builder operations (arithmetic with its constant-folding shortcuts, booleans, selects, equality, bit splits, hashes,
+    swapped permutations, hinted inverses, connects), evaluated natively next to the builder calls (qpc_test_random_circuit): the generated
+    witness must reproduce every natively computed value, satisfy every gate and copy constraint, and prove."""
+    c, inputs, expected = BuiltCircuit.random_program(seed, zero_knowledge=bool(seed & 1), num_inputs=8 + seed, num_ops=150 + 40 * seed)
+    assert c.num_inputs == len(inputs) and c.desc.num_public_inputs == len(expected) > 20
+    w, p = c.witness(inputs, bytes(range(32)))
+    assert list(p) == list(expected)
+    oc = OracleCircuit(c.desc)
+    assert check_witness(oc, w, p) is None
+    if seed < 3:
+        salts = SynthCircuit("B").salts_keyed(TEST_SALT_KEY, seed) if c.desc.zero_knowledge else None
+        if not c.desc.zero_knowledge or c.desc.degree_bits == 14:
+            assert oc.verify(oc.prove(w, p, salts=salts)) is None
+    bad = inputs.copy(); bad[0] = (int(bad[0]) + 1) % P                           # other inputs: other values (or a failed connect / hint), never the same outputs
+    try:
+        _, p2 = c.witness(bad, bytes(range(32)))
+        assert list(p2) != list(expected)
+    except CircuitError:
+        pass

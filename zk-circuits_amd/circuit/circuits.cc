@@ -308,3 +308,71 @@ int qpv_fill_targets(const qpv_vote_inputs* in, uint64_t* inputs, size_t cap, si
 void qpc_hash_no_pad(const uint64_t* felts, size_t count, uint64_t out[4]) { hash_no_pad(felts, count, out); }
 
 } // extern "C"
+
+// ---- test hook (include/qpcircuit_internal.h): random builder programs with a native shadow evaluation
+#include "../../include/qpcircuit_internal.h"
+extern "C" int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, uint32_t num_inputs, uint32_t num_ops, qpc_circuit** out, uint64_t* inputs,
+                                       uint64_t* expected, size_t cap, size_t* num_outputs) { return guard([&]() -> int {
+  using namespace qp;
+  if (!out || !inputs || !expected || !num_outputs || num_inputs < 2) return fail(QPGPU_ERR_ARG, "bad argument");
+  u64 s = seed * 0x9E3779B97F4A7C15ULL + 0x5157;
+  auto next = [&]() { u64 z = (s += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
+  auto felt = [&]() { u64 v = next(); return v >= P ? v - P : v; };
+  std::unique_ptr<qpc_circuit> c(new qpc_circuit(QPC_AGGREGATION + 1, zero_knowledge != 0));
+  Builder& b = c->b;
+  std::vector<Target> t; std::vector<u64> v;                    // targets and their native values
+  for (uint32_t i = 0; i < num_inputs; i++) {
+    u64 x = next() % 5 == 0 ? next() % 4 : (next() % 3 == 0 ? next() & 0xFFFFFFFFULL : felt());      // bits, 32-bit values and full field elements
+    inputs[i] = x; t.push_back(b.add_input()); v.push_back(x);
+  }
+  auto pick = [&]() { return (size_t)(next() % t.size()); };
+  auto push = [&](Target tt, u64 vv) { t.push_back(tt); v.push_back(vv); };
+  auto as_bool = [&](size_t i) { BoolT r = b.is_equal(t[i], b.zero()); return std::make_pair(r, (u64)(v[i] == 0)); };   // a boolean derived from any value
+  for (uint32_t op = 0; op < num_ops; op++) {
+    const size_t i = pick(), j = pick(), k = pick();
+    switch (next() % 16) {
+      case 0: push(b.add(t[i], t[j]), gl_add(v[i], v[j])); break;
+      case 1: push(b.sub(t[i], t[j]), gl_sub(v[i], v[j])); break;
+      case 2: push(b.mul(t[i], t[j]), gl_mul(v[i], v[j])); break;
+      case 3: { u64 cst = next() % 3 == 0 ? next() % 3 : felt(); push(b.mul_const(cst, t[i]), gl_mul(cst, v[i])); break; }
+      case 4: push(b.mul_add(t[i], t[j], t[k]), gl_add(gl_mul(v[i], v[j]), v[k])); break;
+      case 5: { u64 k0 = next() % 4 == 0 ? next() % 2 : felt(), k1 = next() % 4 == 0 ? next() % 2 : felt();
+                push(b.arithmetic(k0, k1, t[i], t[j], t[k]), gl_add(gl_mul(k0, gl_mul(v[i], v[j])), gl_mul(k1, v[k]))); break; }
+      case 6: { u64 cst = next() % 4 == 0 ? next() % 2 : felt(); push(b.constant(cst), cst); break; }
+      case 7: { auto e = b.is_equal(t[i], t[j]); push(e.t, (u64)(v[i] == v[j])); break; }
+      case 8: { auto bi = as_bool(i); push(b.select(bi.first, t[j], t[k]), bi.second ? v[j] : v[k]); break; }
+      case 9: { auto bi = as_bool(i), bj = as_bool(j); u64 w = next() % 3;
+                BoolT r = w == 0 ? b.and_(bi.first, bj.first) : (w == 1 ? b.or_(bi.first, bj.first) : b.not_(bi.first));
+                push(r.t, w == 0 ? (bi.second & bj.second) : (w == 1 ? (bi.second | bj.second) : (1 - bi.second))); break; }
+      case 10: {                                                  // split a 32-bit truncation and recombine two of its bit ranges
+        Target hi_, lo_; b.lohi_hint(t[i], lo_, hi_);
+        b.connect(b.arithmetic(u64(1) << 32, 1, hi_, b.one(), lo_), t[i]); b.range_check(hi_, 32);
+        const u64 lov = v[i] & 0xFFFFFFFFULL;
+        std::vector<BoolT> bits = b.split_le(lo_, 32);
+        Target acc = b.zero(); u64 accv = 0; const int from = (int)(next() % 20), len = 1 + (int)(next() % 12);
+        for (int q = len - 1; q >= 0; q--) { acc = b.arithmetic(2, 1, acc, b.one(), bits[from + q].t); accv = 2 * accv + ((lov >> (from + q)) & 1); }
+        push(acc, accv); push(hi_, v[i] >> 32); break;
+      }
+      case 11: { std::vector<Target> in; std::vector<u64> inv; const int n = 1 + (int)(next() % 19);
+                 for (int q = 0; q < n; q++) { size_t z = pick(); in.push_back(t[z]); inv.push_back(v[z]); }
+                 Hash4 h = b.hash_n_to_hash_no_pad(in); u64 hv[4]; hash_no_pad(inv.data(), inv.size(), hv);
+                 for (int q = 0; q < 4; q++) push(h.e[q], hv[q]); break; }
+      case 12: { auto bi = as_bool(i); Target st[12]; u64 sv[12];
+                 for (int q = 0; q < 12; q++) { size_t z = pick(); st[q] = t[z]; sv[q] = v[z]; }
+                 b.permute_swap(st, bi.first);
+                 if (bi.second) for (int q = 0; q < 4; q++) std::swap(sv[q], sv[q + 4]);
+                 poseidon_permute(sv);
+                 for (int q = 0; q < 12; q += 5) push(st[q], sv[q]); break; }
+      case 13: { Target a = b.add(t[i], t[j]), a2 = b.add(t[j], t[i]); b.connect(a, a2); push(a2, gl_add(v[i], v[j])); break; }   // equal by construction
+      case 14: if (v[i]) { Target iv = b.inverse_hint(t[i]); b.connect(b.mul(iv, t[i]), b.one()); push(iv, gl_inv(v[i])); } break;
+      default: { Target ia, ib; b.ext_inverse_hint(t[i], t[j], ia, ib);
+                 const u64 nrm = gl_sub(gl_sqr(v[i]), gl_mul(7, gl_sqr(v[j])));
+                 if (nrm) { const u64 ni = gl_inv(nrm); push(ia, gl_mul(v[i], ni)); push(ib, gl_mul(gl_sub(0, v[j]), ni)); } break; }
+    }
+  }
+  size_t n_out = 0;
+  for (size_t i = num_inputs; i < t.size() && n_out < cap; i += 1 + next() % 3) { b.register_public_input(t[i]); expected[n_out++] = v[i]; }
+  *num_outputs = n_out;
+  b.build();
+  *out = c.release(); return 0;
+}); }

@@ -223,6 +223,8 @@ def circuit_lib():
         L.qpc_aggregation_circuit_build.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         L.qpc_aggregation_fill_targets.argtypes = [ctypes.c_void_p, u64p, u64p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, u64p,
                                                    ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.qpc_test_random_circuit.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), u64p, u64p,
+                                              ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.qpc_hash_no_pad.restype = None
         L.qpc_hash_no_pad.argtypes = [u64p, ctypes.c_size_t, u64p]
         _circuit = L
@@ -280,6 +282,23 @@ class BuiltCircuit:
         self.N = self.n << self.desc.fri_rate_bits
         self.W = self.desc.num_wires
         self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
+
+    @classmethod
+    def random_program(cls, seed, zero_knowledge=False, num_inputs=12, num_ops=300):
+        """Test hook (include/qpcircuit_internal.h): a circuit of random builder operations; returns (circuit, input values, natively computed
+        values of its public inputs)."""
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        inputs = np.zeros(num_inputs, dtype=np.uint64); expected = np.zeros(8 * num_ops + 64, dtype=np.uint64); n = ctypes.c_size_t()
+        circuit_check(circuit_lib().qpc_test_random_circuit(seed, 1 if zero_knowledge else 0, num_inputs, num_ops, ctypes.byref(h), ptr(inputs), ptr(expected),
+                                                            len(expected), ctypes.byref(n)))
+        self.handle, self.kind = h, -1
+        self.desc = circuit_lib().qpc_circuit_desc(h).contents
+        self.n = 1 << self.desc.degree_bits
+        self.N = self.n << self.desc.fri_rate_bits
+        self.W = self.desc.num_wires
+        self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
+        return self, inputs, expected[:n.value]
 
     @classmethod
     def aggregation(cls, inner_desc, num_proofs):
