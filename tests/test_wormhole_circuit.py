@@ -42,8 +42,8 @@ def test_test_helpers_hold_the_reference_fixture_values():
     assert th.DEFAULT_ROOT_HASH == KATS["default_root_hash"] and th.DEFAULT_FUNDING_AMOUNT == KATS["expected_funding_amount"]
 
 
-@pytest.mark.parametrize("kind", [QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_EXIT_ACCOUNT, QPC_WORMHOLE])
-@pytest.mark.parametrize("zk", [False, True])
+@pytest.mark.parametrize("kind,zk", [(QPC_NULLIFIER, False), (QPC_UNSPENDABLE_ACCOUNT, False), (QPC_STORAGE_PROOF, False), (QPC_EXIT_ACCOUNT, False),
+                                     (QPC_WORMHOLE, False), (QPC_NULLIFIER, True), (QPC_WORMHOLE, True)])     # zk: 2^14 rows each (seconds of oracle set-up): two of them
 def test_fragment_witness_satisfies_every_constraint(circuits, kind, zk):
     """build_and_verify_*_proof of each *_tests.rs: the fragment alone with the shared test inputs."""
     c, oc = circuits(kind, zk)
@@ -315,16 +315,14 @@ def test_builder_fuzz_random_programs(seed):
     """Random programs of builder operations (arithmetic with its constant-folding shortcuts, booleans, selects, equality, bit splits, hashes,
     swapped permutations, hinted inverses, connects), evaluated natively next to the builder calls (qpc_test_random_circuit): the generated
     witness must reproduce every natively computed value, satisfy every gate and copy constraint, and prove."""
-    c, inputs, expected = BuiltCircuit.random_program(seed, zero_knowledge=bool(seed & 1), num_inputs=8 + seed, num_ops=150 + 40 * seed)
+    c, inputs, expected = BuiltCircuit.random_program(seed, zero_knowledge=(seed == 1), num_inputs=8 + seed, num_ops=150 + 40 * seed)
     assert c.num_inputs == len(inputs) and c.desc.num_public_inputs == len(expected) > 20
     w, p = c.witness(inputs, bytes(range(32)))
     assert list(p) == list(expected)
     oc = OracleCircuit(c.desc)
     assert check_witness(oc, w, p) is None
-    if seed < 3:
-        salts = SynthCircuit("B").salts_keyed(TEST_SALT_KEY, seed) if c.desc.zero_knowledge else None
-        if not c.desc.zero_knowledge or c.desc.degree_bits == 14:
-            assert oc.verify(oc.prove(w, p, salts=salts)) is None
+    if seed in (0, 2):
+        assert oc.verify(oc.prove(w, p)) is None
     bad = inputs.copy(); bad[0] = (int(bad[0]) + 1) % P                           # other inputs: other values (or a failed connect / hint), never the same outputs
     try:
         _, p2 = c.witness(bad, bytes(range(32)))
