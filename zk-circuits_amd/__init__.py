@@ -14,6 +14,7 @@ from .prover import (CircuitConfig, SyntheticInputs, ProofWithPublicInputs, Worm
                      WormholeCircuitData)
 from .inputs import (BytesDigest, CircuitInputs, PublicCircuitInputs, PrivateCircuitInputs, ProcessedStorageProof,  # noqa: F401
                      VoteCircuitData, VotePublicInputs, VotePrivateInputs, nullifier_from_preimage, unspendable_account_from_secret)
+from . import test_helpers  # noqa: F401
 from .verifier import WormholeVerifier  # noqa: F401
 from .circuit_builder import generate_circuit_binaries  # noqa: F401
 from .aggregator import (WormholeProofAggregator, TreeAggregationConfig, AggregatedLeaves, AggregatedProof,  # noqa: F401
