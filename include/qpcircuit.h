@@ -47,6 +47,12 @@ void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]);
  * blinding_key: 32 secret bytes seeding the zk blinding rows (may be NULL for a non-zk circuit); wires [135][n] column-major, public_inputs
  * [desc->num_public_inputs]. QPGPU_ERR_WITNESS when the inputs do not satisfy the circuit (qpc_last_error names the conflict). */
 int qpc_generate_witness(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs);
+/* The same with an explicit number of host threads (0 = up to 8, what qpc_generate_witness uses; 1 = in program order on the caller's thread).
+ * Circuits declare independent segments when they are built (a node's children and their FRI queries, the storage proof's nodes); a circuit
+ * without them, or whose segments turn out not to be independent, is generated on one thread whatever is asked (qpc_circuit_parallel_segments). */
+int qpc_generate_witness_mt(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs,
+                            uint32_t threads);
+int qpc_circuit_parallel_segments(const qpc_circuit* c);
 const char* qpc_last_error(void);
 
 /* ---- wormhole inputs (wormhole/circuit/src/inputs.rs:23-55). 32-byte digests are BytesDigest: four little-endian u64, each < p. */

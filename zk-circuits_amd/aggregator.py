@@ -211,10 +211,14 @@ class RecursiveChunkProver:
         while len(pool) < len(chunks):
             pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
 
+        cores = len(os.sched_getaffinity(0))
+        outer = 1 if len(chunks) == 1 else min(len(chunks), max(2, cores // 2))           # nodes generated at once
+        inner = max(1, min(8, cores // outer))                                            # threads inside one node (its children / their FRI queries)
+
         def witness(chunk, slot=0):
             raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunk]
             try:
-                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key, out=pool[slot])
+                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key, out=pool[slot], threads=inner)
             except ffi.CircuitError as e:
                 raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
         salt_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
@@ -238,7 +242,7 @@ class RecursiveChunkProver:
         # the host generates the next ones
         from concurrent.futures import ThreadPoolExecutor
         out = []
-        with ThreadPoolExecutor(max_workers=min(len(chunks), max(2, len(os.sched_getaffinity(0)) // 2))) as ex:
+        with ThreadPoolExecutor(max_workers=outer) as ex:
             futures = [ex.submit(witness, c, i) for i, c in enumerate(chunks)]
             for first in range(0, len(chunks), self.GROUP):
                 out += prove([f.result() for f in futures[first:first + self.GROUP]], first)

@@ -2,6 +2,7 @@
 #include "builder.h"
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cstring>
 #include <thread>
 #include <cstdio>
@@ -62,6 +63,55 @@ void Builder::build() {
   std::sort(wire_targets_.begin(), wire_targets_.end(), [&](Target a, Target b) { return cells_[a].col != cells_[b].col ? cells_[a].col < cells_[b].col : cells_[a].row < cells_[b].row; });
   fill_dst_.reserve(wire_targets_.size()); fill_cls_.reserve(wire_targets_.size());
   for (Target t : wire_targets_) { fill_dst_.push_back((uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row)); fill_cls_.push_back(cls_[t]); }
+
+  // replay phases (builder.h begin_segment): partition the operations and check that the segments are independent as declared
+  { seg_ops_[1].assign(seg_count_[1], {}); seg_ops_[2].assign(seg_count_[2], {});
+    // first writer of every class in program order: 0 = input / constant / leading operation, else 1 + stage * 2^28 + segment; post = ~0
+    std::vector<uint32_t> writer(ncls_, UINT32_MAX - 1);                 // UINT32_MAX - 1: not written yet
+    for (Target t : inputs_) writer[cls_[t]] = 0;
+    bool seen_segment = false, ok = true;
+    auto reads = [&](const Op& op, std::vector<Target>& in) {
+      in.clear();
+      switch (op.kind) {
+        case OP_ARITH: in = {op.a, op.b, op.c}; break;
+        case OP_INV: case OP_LOHI: in = {op.a}; break;
+        case OP_EXTINV: in = {op.a, op.b}; break;
+        case OP_SPLIT: in = {op.out}; break;
+        case OP_POSEIDON: for (int i = 0; i < 13; i++) in.push_back(op.out + i); break;
+        default: break;
+      }
+    };
+    auto writes = [&](const Op& op, std::vector<Target>& out) {
+      out.clear();
+      switch (op.kind) {
+        case OP_CONST: case OP_ARITH: case OP_INV: out = {op.out}; break;
+        case OP_LOHI: case OP_EXTINV: out = {op.out, op.c}; break;
+        case OP_SPLIT: for (int l = 0; l < BASESUM_LIMBS; l++) out.push_back(op.out + 1 + l); break;
+        case OP_POSEIDON: for (int i = 0; i < 12; i++) out.push_back(op.out + 13 + i); break;
+      }
+    };
+    std::vector<Target> tmp;
+    for (const Op& op : ops_) if (op.kind == OP_CONST) writer[cls_[op.out]] = 0;       // constants are replayed first
+    for (uint32_t i = 0; i < ops_.size(); i++) {
+      const Op& op = ops_[i];
+      if (op.kind == OP_CONST) { const_ops_.push_back(i); continue; }
+      uint32_t me;
+      if (op.stage == 0) { me = seen_segment ? UINT32_MAX : 0; (seen_segment ? post_ops_ : pre_ops_).push_back(i); }
+      else { seen_segment = true; me = 1 + ((uint32_t)op.stage << 28) + op.seg; seg_ops_[op.stage][op.seg].push_back(i); }
+      reads(op, tmp);
+      for (Target t : tmp) {
+        const uint32_t w = writer[cls_[t]];
+        bool legal = w == 0 || w == me || me == UINT32_MAX;               // leading data, own segment, or a trailing operation (runs last)
+        if (!legal && op.stage == 2 && w != UINT32_MAX && w != UINT32_MAX - 1 && (w - 1) >> 28 == 1) legal = true;   // stage 2 may read stage 1
+        if (!legal) { if (ok && getenv("QPC_TIMING")) fprintf(stderr, "  segments not independent: op %u (kind %d, stage %d seg %u) reads a class first written by %x\n", i, op.kind, op.stage, op.seg, w); ok = false; }
+      }
+      writes(op, tmp);
+      for (Target t : tmp) if (writer[cls_[t]] == UINT32_MAX - 1) writer[cls_[t]] = me;
+    }
+    parallel_ok_ = ok && seen_segment;
+    if (getenv("QPC_TIMING")) { size_t s1 = 0, s2 = 0; for (auto& v : seg_ops_[1]) s1 += v.size(); for (auto& v : seg_ops_[2]) s2 += v.size();
+      fprintf(stderr, "  replay phases: %zu constants, %zu leading, %zu in %zu stage-1 segments, %zu in %zu stage-2 segments, %zu trailing; parallel %d\n",
+              const_ops_.size(), pre_ops_.size(), s1, seg_ops_[1].size(), s2, seg_ops_[2].size(), post_ops_.size(), (int)parallel_ok_); } }
 
   // sigma: the routed cells of a class form one cycle; a blinding pair swaps its two cells
   std::vector<uint32_t> sigma((size_t)R * n_);
@@ -130,7 +180,7 @@ void Builder::build() {
     memcpy(d.circuit_digest, acc, sizeof acc); }
   lapb("digest");
   // build-time indexes are not needed to generate witnesses
-  wire_ids_ = {}; arith_cache_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
+  wire_ids_ = {}; arith_cache_ = {}; out_phase_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
   built_ = true;
   lapb("free");
 }
@@ -163,7 +213,7 @@ static void salt_blocks8(const SaltKey& key, u64 nonce, u64 block0, u64* out) {
   for (int l = 0; l < 8; l++) salt_block(key, nonce, block0 + l, out + 8 * l);
 }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const {
+std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs, int threads) const {
   const size_t n = n_; static const bool tm = getenv("QPC_TIMING") != nullptr; double t0 = now_ms();      // QPC_TIMING (debug): per-phase times on stderr
   auto lap = [&](const char* what) { if (tm) { double t = now_ms(); fprintf(stderr, "  %-12s %.3f ms\n", what, t - t0); t0 = t; } };
   const u64 UNSET = ~u64(0);                                          // not a field element: marks a class no generator has written yet
@@ -181,63 +231,112 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
     return v;
   };
   if (zk_ && !blinding_key) return "a zero-knowledge circuit needs a blinding key";
-  // Zeroing the matrix and writing the zk blinding rows (ChaCha8 keystream) touch no class value: they run beside the operation replay.
-  auto zero_and_blind = [&]() {
-    memset(wires, 0, sizeof(u64) * (size_t)W * n);
+  // Zeroing the matrix and writing the zk blinding rows (ChaCha8 keystream, one stream per wire column) touch no class value: they run
+  // beside the operation replay, column ranges on up to four helper threads.
+  auto zero_and_blind = [&](int c_lo, int c_hi) {
+    memset(wires + (size_t)c_lo * n, 0, sizeof(u64) * (size_t)(c_hi - c_lo) * n);
     if (!zk_) return;
     const SaltKey key = salt_key_from_bytes(blinding_key);
-    u64 blk[64]; u64 nblk = 0; int pos = 64;
-    auto rnd = [&]() { if (pos == 64) { salt_blocks8(key, 0x626c696e64ULL /* "blind" */, nblk, blk); nblk += 8; pos = 0; } return blk[pos++]; };
-    for (int c = 0; c < W; c++) {                                     // column by column: sequential writes
+    for (int c = c_lo; c < c_hi; c++) {                               // column by column: sequential writes
+      u64 blk[64]; u64 nblk = 0; int pos = 64;
+      auto rnd = [&]() { if (pos == 64) { salt_blocks8(key, 0x626c696e6400ULL /* "blind" */ + (u64)c, nblk, blk); nblk += 8; pos = 0; } return blk[pos++]; };
       u64* col = wires + (size_t)c * n;
       for (size_t r = 0; r < blind_plain_; r++) col[blind_plain_first_ + r] = rnd();
       if (c < R) for (size_t p = 0; p < blind_pairs_; p++) { const u64 v = rnd(); col[blind_pair_first_ + 2 * p] = v; col[blind_pair_first_ + 2 * p + 1] = v; }
     }
   };
-  struct Joiner { std::thread t; void join() { if (t.joinable()) t.join(); } ~Joiner() { join(); } } bg;
-  if (zk_) bg.t = std::thread(zero_and_blind); else zero_and_blind();
+  struct Joiner { std::vector<std::thread> t; void join() { for (auto& x : t) if (x.joinable()) x.join(); } ~Joiner() { join(); } } bg;
+  if (zk_) { const int nb = threads > 1 ? std::min(4, threads) : 1; for (int k = 0; k < nb; k++) bg.t.emplace_back(zero_and_blind, W * k / nb, W * (k + 1) / nb); }
+  else zero_and_blind(0, W);
   for (size_t i = 0; i < inputs_.size(); i++) {
     if (inputs[i] >= P) return "input target " + std::to_string(i) + " is not a canonical field element";
     if (!set(inputs_[i], inputs[i])) return err;
   }
-  std::unordered_map<u64, u64> inv_cache;
-  std::vector<u64> ptrace;                                            // per Poseidon row: row index, then wire columns 29..134
-  for (const Op& op : ops_) {
+  // one replay worker: its own error, inverse cache and Poseidon traces; class values are shared (segments write disjoint classes, and
+  // re-writing a class with the value it holds stores nothing)
+  static const u64 SMALL_INV = 1024;
+  static const std::vector<u64> small_inv = [] {                      // 1/1 .. 1/1024 by one inversion (Montgomery's trick)
+    std::vector<u64> pre(SMALL_INV + 2, 1), out(SMALL_INV + 1, 0);
+    for (u64 i = 1; i <= SMALL_INV; i++) pre[i + 1] = gl_mul(pre[i], i);
+    u64 inv = gl_inv(pre[SMALL_INV + 1]);
+    for (u64 i = SMALL_INV; i >= 1; i--) { out[i] = gl_mul(inv, pre[i]); inv = gl_mul(inv, i); }
+    return out;
+  }();
+  struct Worker { std::string err; std::unordered_map<u64, u64> inv_cache; std::vector<u64> ptrace; };
+  u64* const vals = val.data();
+  auto exec = [&](const Op& op, Worker& wk) {
+    auto wset = [&](Target t, u64 v) {
+      u64* slot = vals + cls_[t]; const u64 cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+      if (cur == v) return;
+      if (__builtin_expect(cur != UNSET, 0)) { if (wk.err.empty()) wk.err = "copy-constrained targets set twice with different values: " + name(t) + " was " + std::to_string(cur) + ", now " + std::to_string(v); return; }
+      __atomic_store_n(slot, v, __ATOMIC_RELAXED);
+    };
+    auto wget = [&](Target t) -> u64 {
+      const u64 v = __atomic_load_n(vals + cls_[t], __ATOMIC_RELAXED);
+      if (__builtin_expect(v == UNSET, 0)) { if (wk.err.empty()) wk.err = name(t) + " is read before any generator has set it"; return 0; }
+      return v;
+    };
     switch (op.kind) {
-      case OP_CONST: set(op.out, op.k0); break;
-      case OP_ARITH: { const u64 a = get(op.a), b = get(op.b), c = get(op.c); set(op.out, gl_add(gl_mul(op.k0, gl_mul(a, b)), gl_mul(op.k1, c))); break; }
+      case OP_CONST: wset(op.out, op.k0); break;
+      case OP_ARITH: { const u64 a = wget(op.a), b = wget(op.b), c = wget(op.c); wset(op.out, gl_add(gl_mul(op.k0, gl_mul(a, b)), gl_mul(op.k1, c))); break; }
       case OP_INV: {                                                 // is_equal hints: the differences repeat (index - j over all nodes), so inverses are cached
-        const u64 a = get(op.a); u64 r = 0;
-        if (a) { auto it = inv_cache.find(a); if (it != inv_cache.end()) r = it->second; else { r = gl_inv(a); inv_cache.emplace(a, r); } }
-        set(op.out, r); break;
+        const u64 a = wget(op.a); u64 r = 0;
+        if (a && a <= SMALL_INV) r = small_inv[a];                                    // differences of small indices (is_equal(j, index)): a table
+        else if (a && P - a <= SMALL_INV) r = P - small_inv[P - a];
+        else if (a) { auto it = wk.inv_cache.find(a); if (it != wk.inv_cache.end()) r = it->second; else { r = gl_inv(a); wk.inv_cache.emplace(a, r); } }
+        wset(op.out, r); break;
       }
       case OP_SPLIT: {
-        const u64 x = get(op.out);
-        if (x >> BASESUM_LIMBS) { if (err.empty()) err = "range check: " + std::to_string(x) + " does not fit " + std::to_string(BASESUM_LIMBS) + " binary limbs"; break; }
-        for (int l = 0; l < BASESUM_LIMBS; l++) set(op.out + 1 + l, (x >> l) & 1);
+        const u64 x = wget(op.out);
+        if (x >> BASESUM_LIMBS) { if (wk.err.empty()) wk.err = "range check: " + std::to_string(x) + " does not fit " + std::to_string(BASESUM_LIMBS) + " binary limbs"; break; }
+        for (int l = 0; l < BASESUM_LIMBS; l++) wset(op.out + 1 + l, (x >> l) & 1);
         break;
       }
       case OP_POSEIDON: {                                           // targets of the row: inputs out..out+11, swap out+12, outputs out+13..out+24
-        u64 st[12]; for (int i = 0; i < 12; i++) st[i] = get(op.out + i);
-        const u64 swap = get(op.out + 12);
-        if (swap > 1) { if (err.empty()) err = "Poseidon gate row " + std::to_string(op.row) + ": swap wire is not a bit"; break; }
+        u64 st[12]; for (int i = 0; i < 12; i++) st[i] = wget(op.out + i);
+        const u64 swap = wget(op.out + 12);
+        if (swap > 1) { if (wk.err.empty()) wk.err = "Poseidon gate row " + std::to_string(op.row) + ": swap wire is not a bit"; break; }
         if (swap) for (int i = 0; i < 4; i++) std::swap(st[i], st[i + 4]);
-        ptrace.resize(ptrace.size() + 108); ptrace[ptrace.size() - 108] = op.row; ptrace[ptrace.size() - 107] = swap;
-        poseidon_permute_traced(st, ptrace.data() + ptrace.size() - 106);      // the row's S-box input wires, kept for the fill below
-        for (int i = 0; i < 12; i++) set(op.out + 13 + i, st[i]);
+        wk.ptrace.resize(wk.ptrace.size() + 108); wk.ptrace[wk.ptrace.size() - 108] = op.row; wk.ptrace[wk.ptrace.size() - 107] = swap;
+        poseidon_permute_traced(st, wk.ptrace.data() + wk.ptrace.size() - 106);      // the row's S-box input wires, kept for the fill below
+        for (int i = 0; i < 12; i++) wset(op.out + 13 + i, st[i]);
         break;
       }
-      case OP_LOHI: { const u64 x = get(op.a); set(op.out, x & 0xFFFFFFFFULL); set(op.c, x >> 32); break; }
+      case OP_LOHI: { const u64 x = wget(op.a); wset(op.out, x & 0xFFFFFFFFULL); wset(op.c, x >> 32); break; }
       case OP_EXTINV: {                                             // (a + b*sqrt7)^-1 = (a - b*sqrt7) / (a^2 - 7 b^2)
-        const u64 a = get(op.a), b = get(op.b);
+        const u64 a = wget(op.a), b = wget(op.b);
         const u64 norm = gl_sub(gl_sqr(a), gl_mul(7, gl_sqr(b)));
         const u64 ni = norm ? gl_inv(norm) : 0;
-        set(op.out, gl_mul(a, ni)); set(op.c, gl_mul(gl_sub(0, b), ni));
+        wset(op.out, gl_mul(a, ni)); wset(op.c, gl_mul(gl_sub(0, b), ni));
         break;
       }
     }
-    if (!err.empty()) return err;
+  };
+  const int nthr = parallel_ok_ ? std::max(1, std::min(threads, 32)) : 1;
+  std::vector<Worker> workers((size_t)nthr);
+  auto run_list = [&](const std::vector<uint32_t>& idx, Worker& wk) { for (uint32_t i : idx) { exec(ops_[i], wk); if (!wk.err.empty()) return; } };
+  auto run_stage = [&](const std::vector<std::vector<uint32_t>>& segs) {           // segments of one stage over the workers (dynamic hand-out)
+    if (segs.empty()) return;
+    std::atomic<size_t> next{0};
+    auto body = [&](Worker& wk) { for (size_t k; (k = next.fetch_add(1)) < segs.size();) { run_list(segs[k], wk); if (!wk.err.empty()) return; } };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; t++) pool.emplace_back(body, std::ref(workers[(size_t)t]));
+    body(workers[0]);
+    for (auto& th : pool) th.join();
+  };
+  auto first_error = [&]() { for (auto& wk : workers) if (!wk.err.empty()) return wk.err; return std::string(); };
+  if (nthr > 1) {
+    run_list(const_ops_, workers[0]); run_list(pre_ops_, workers[0]);
+    if (first_error().empty()) run_stage(seg_ops_[1]);
+    if (first_error().empty()) run_stage(seg_ops_[2]);
+    if (first_error().empty()) run_list(post_ops_, workers[0]);
+  } else {
+    for (const Op& op : ops_) { exec(op, workers[0]); if (!workers[0].err.empty()) break; }     // program order
   }
+  err = first_error();
+  if (!err.empty()) return err;
+  std::vector<u64> ptrace;
+  for (auto& wk : workers) { if (ptrace.empty()) ptrace.swap(wk.ptrace); else ptrace.insert(ptrace.end(), wk.ptrace.begin(), wk.ptrace.end()); }
   for (size_t i = 0; i < public_inputs_.size(); i++) public_inputs[i] = get(public_inputs_[i]);
   if (!err.empty()) return err;
   lap("ops");

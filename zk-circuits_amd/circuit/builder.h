@@ -91,7 +91,7 @@ class Builder {
     (const_slot_ == 0 ? row_c0_ : row_c1_)[const_row_] = c;
     const_slot_ ^= 1;
     consts_[c] = t; const_val_[t] = c;
-    ops_.push_back(Op{OP_CONST, t, 0, 0, 0, c, 0, 0});
+    rec(Op{OP_CONST, t, 0, 0, 0, c, 0, 0});
     return t;
   }
   Target zero() const { return zero_; }
@@ -118,15 +118,19 @@ class Builder {
     }
     if (find(a) > find(b)) std::swap(a, b);                 // the product commutes: one cache entry per unordered pair
     auto key = std::make_tuple(k0, k1, find(a), find(b), find(c));
-    auto hit = arith_cache_.find(key); if (hit != arith_cache_.end()) return hit->second;
+    auto hit = arith_cache_.find(key);
+    if (hit != arith_cache_.end()) {                        // reuse, unless that would tie two independent segments together (then: a second slot)
+      const uint32_t ph = out_phase_[hit->second], me = phase_code();
+      if (ph == 0 || ph == me || (cur_stage_ == 2 && (ph >> 28) == 1) || cur_stage_ == 0) return hit->second;
+    }
     auto& open = open_arith_[std::make_pair(k0, k1)];
     if (open.second == 0) { open.first = add_row(K_ARITH, k0, k1); }
     const uint32_t row = open.first; const int s = open.second;
     open.second = (s + 1) % ARITH_OPS;
     unite(wire(row, 4 * s), a); unite(wire(row, 4 * s + 1), b); unite(wire(row, 4 * s + 2), c);
     Target out = wire(row, 4 * s + 3);
-    ops_.push_back(Op{OP_ARITH, out, wire(row, 4 * s), wire(row, 4 * s + 1), wire(row, 4 * s + 2), k0, k1, 0});
-    arith_cache_[key] = out;
+    rec(Op{OP_ARITH, out, wire(row, 4 * s), wire(row, 4 * s + 1), wire(row, 4 * s + 2), k0, k1, 0});
+    arith_cache_[key] = out; out_phase_[out] = phase_code();
     return out;
   }
   Target add(Target a, Target b) { return arithmetic(1, 1, a, one_, b); }
@@ -145,7 +149,7 @@ class Builder {
     u64 vd;
     if (is_const(diff, vd)) return constant_bool(vd == 0);
     Target inv = add_virtual();
-    ops_.push_back(Op{OP_INV, inv, diff, 0, 0, 0, 0, 0});
+    rec(Op{OP_INV, inv, diff, 0, 0, 0, 0, 0});
     Target ne = mul(diff, inv);
     Target eq = sub(one_, ne);
     assert_zero(mul(diff, eq));
@@ -155,19 +159,19 @@ class Builder {
   // Hint: the inverse of a + b*sqrt(7) in F_{p^2} (0 for 0) as two virtual targets; the caller constrains it.
   void ext_inverse_hint(Target a, Target b, Target& ia, Target& ib) {
     ia = add_virtual(); ib = add_virtual();
-    ops_.push_back(Op{OP_EXTINV, ia, a, b, ib, 0, 0, 0});
+    rec(Op{OP_EXTINV, ia, a, b, ib, 0, 0, 0});
   }
   // Hint: the low and high 32-bit halves of the canonical value of x; the caller constrains them.
-  void lohi_hint(Target x, Target& lo, Target& hi) { lo = add_virtual(); hi = add_virtual(); ops_.push_back(Op{OP_LOHI, lo, x, 0, hi, 0, 0, 0}); }
+  void lohi_hint(Target x, Target& lo, Target& hi) { lo = add_virtual(); hi = add_virtual(); rec(Op{OP_LOHI, lo, x, 0, hi, 0, 0, 0}); }
   // Hint: the inverse of a base-field target (0 for 0); the caller constrains it.
-  Target inverse_hint(Target a) { Target inv = add_virtual(); ops_.push_back(Op{OP_INV, inv, a, 0, 0, 0, 0, 0}); return inv; }
+  Target inverse_hint(Target a) { Target inv = add_virtual(); rec(Op{OP_INV, inv, a, 0, 0, 0, 0, 0}); return inv; }
 
   // Little-endian bits of x, which must be < 2^nbits: one BaseSum<2> row (wire 0 = sum, wires 1..63 = limbs, each constrained to {0,1});
   // limbs from nbits up are tied to zero.
   std::vector<BoolT> split_le(Target x, int nbits) {
     const uint32_t row = add_row(K_BASESUM, 0, 0);
     unite(wire(row, 0), x);
-    ops_.push_back(Op{OP_SPLIT, wire(row, 0), 0, 0, 0, 0, 0, row});
+    rec(Op{OP_SPLIT, wire(row, 0), 0, 0, 0, 0, 0, row});
     std::vector<BoolT> bits;
     for (int l = 0; l < BASESUM_LIMBS; l++) { Target t = wire(row, 1 + l); if (l < nbits) bits.push_back(BoolT{t}); else assert_zero(t); }
     return bits;
@@ -182,7 +186,7 @@ class Builder {
     const Target first = wire(row, 0);                      // targets of a fresh row are numbered in creation order: inputs first .. first+11,
     for (int i = 0; i < 12; i++) unite(wire(row, i), st[i]);
     unite(wire(row, 24), swap.t);                           // swap first+12,
-    ops_.push_back(Op{OP_POSEIDON, first, 0, 0, 0, 0, 0, row});
+    rec(Op{OP_POSEIDON, first, 0, 0, 0, 0, 0, row});
     for (int i = 0; i < 12; i++) st[i] = wire(row, 12 + i); // outputs first+13 .. first+24
   }
   Hash4 hash_n_to_hash_no_pad(const std::vector<Target>& in) {
@@ -195,6 +199,14 @@ class Builder {
     return h;
   }
 
+  // ---- independent parts of a circuit, for witness generation on several threads. Operations recorded between begin_segment(stage) and
+  // end_segment() form one segment. Replay order: constants, the operations before the first segment, all stage-1 segments (in parallel), all
+  // stage-2 segments (in parallel), the remaining unsegmented operations. A stage-1 segment may read what constants, inputs, the leading
+  // operations and itself produced; a stage-2 segment also what any stage-1 segment produced. build() checks this on the recorded program and
+  // falls back to in-order replay if it does not hold (the circuit is the same either way).
+  void begin_segment(int stage) { cur_stage_ = (uint8_t)stage; cur_seg_ = seg_count_[stage]++; seen_segment_ = true; }
+  void end_segment() { cur_stage_ = 0; cur_seg_ = 0; }
+
   // ---- finish: public-input hash, zk blinding rows, padding, sigma, descriptor. After this the builder is a circuit.
   void build();
 
@@ -206,13 +218,15 @@ class Builder {
   void row_counts(uint32_t out[K_KINDS]) const { for (int k = 0; k < K_KINDS; k++) out[k] = 0; for (size_t r = 0; r < gate_rows_; r++) out[row_kind_[r]]++; }
   // generate_partial_witness: inputs[num_inputs()] in allocation order -> wires [135][n] column-major, public_inputs[]. `blinding_key`
   // (32 bytes) seeds the zk blinding rows. Returns "" or the failure.
-  std::string generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs) const;
+  std::string generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs, int threads = 1) const;
+  bool parallel_replay() const { return parallel_ok_; }
 
  private:
   enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON, OP_EXTINV, OP_LOHI };
-  struct Op { uint8_t kind; Target out, a, b, c; u64 k0, k1; uint32_t row; };
+  struct Op { uint8_t kind; Target out, a, b, c; u64 k0, k1; uint32_t row; uint8_t stage = 0; uint32_t seg = 0; };
   struct Cell { int32_t row; int16_t col; };
 
+  void rec(Op op) { op.stage = cur_stage_; op.seg = cur_seg_; ops_.push_back(op); }
   Target new_target(int32_t row, int16_t col) { cells_.push_back(Cell{row, col}); parent_.push_back((uint32_t)parent_.size()); return (Target)(cells_.size() - 1); }
   Target wire(uint32_t row, int col) {
     auto key = ((u64)row << 8) | (u64)col;
@@ -242,7 +256,12 @@ class Builder {
   std::map<std::pair<u64, u64>, std::pair<uint32_t, int>> open_arith_;
   std::map<std::tuple<u64, u64, uint32_t, uint32_t, uint32_t>, Target> arith_cache_;
   Target zero_, one_;
+  uint8_t cur_stage_ = 0; uint32_t cur_seg_ = 0, seg_count_[3] = {0, 0, 0}; bool seen_segment_ = false;
+  std::unordered_map<Target, uint32_t> out_phase_;         // arithmetic outputs: where they were recorded (0 leading, stage << 28 | 1 + segment, ~0 trailing)
+  uint32_t phase_code() const { return cur_stage_ ? ((uint32_t)cur_stage_ << 28) | (1 + cur_seg_) : (seen_segment_ ? UINT32_MAX : 0); }
   // after build()
+  bool parallel_ok_ = false;
+  std::vector<uint32_t> const_ops_, pre_ops_, post_ops_; std::vector<std::vector<uint32_t>> seg_ops_[3];      // operation indices per replay phase
   size_t n_ = 0, gate_rows_ = 0, blind_plain_first_ = 0, blind_plain_ = 0, blind_pair_first_ = 0, blind_pairs_ = 0;
   std::vector<uint32_t> cls_; size_t ncls_ = 0;
   std::vector<Target> wire_targets_; std::vector<uint32_t> fill_dst_, fill_cls_;

@@ -6,6 +6,7 @@
 #include "circuit_object.h"
 #include <cstring>
 #include <memory>
+#include <thread>
 
 using namespace qpc;
 using qp::hash_no_pad;
@@ -109,14 +110,18 @@ void storage_proof_circuit(Builder& b, const StorageProofTargets& t) {   // stor
   for (Target x : lf.funding_amount) leaf_vec.push_back(x);
   const Hash4 leaf_inputs_hash = b.hash_n_to_hash_no_pad(leaf_vec);
   const Target two_pow_32 = b.constant(u64(1) << 32);
-  Hash4 prev_hash = t.root_hash;                                  // the first node must hash to the root
   const int n_log = 5;                                            // bits of MAX_PROOF_LEN - 1
+  // Per node, independent of the other nodes (one witness-generation segment each, builder.h begin_segment): is it a proof node / the
+  // node after the last one, its hash, the range checks of its felts, and the child hash it commits to.
+  struct NodeOut { BoolT is_proof_node, is_leaf_node; Hash4 computed, found; };
+  std::vector<NodeOut> nodes(QPW_MAX_PROOF_LEN);
   for (int i = 0; i < QPW_MAX_PROOF_LEN; i++) {
+    b.begin_segment(1);
     const std::vector<Target>& node = t.proof_data[i];
-    const BoolT is_proof_node = is_const_less_than(b, i, t.proof_len, n_log);
-    const BoolT is_leaf_node = b.is_equal(b.constant(i), t.proof_len);
-    const Hash4 computed = b.hash_n_to_hash_no_pad(node);
-    for (int y = 0; y < 4; y++) b.assert_zero(b.mul(b.sub(computed.e[y], prev_hash.e[y]), is_proof_node.t));
+    NodeOut& o = nodes[i];
+    o.is_proof_node = is_const_less_than(b, i, t.proof_len, n_log);
+    o.is_leaf_node = b.is_equal(b.constant(i), t.proof_len);
+    o.computed = b.hash_n_to_hash_no_pad(node);
     // the child hash this node commits to: the 8 32-bit limbs starting at felt index indices[i], recombined little-endian
     Target found[4] = {b.zero(), b.zero(), b.zero(), b.zero()};
     const Target expected_index = t.indices[i];
@@ -129,10 +134,18 @@ void storage_proof_circuit(Builder& b, const StorageProofTargets& t) {   // stor
       }
     }
     for (int j = QPW_PROOF_NODE_MAX_FELTS - 8; j < QPW_PROOF_NODE_MAX_FELTS; j++) b.range_check(node[j], 32);
-    // the node after the last one: the hash found in the leaf node must carry the leaf-inputs hash (limbs 1..3; the first is
-    // partly overwritten by the trie's nibble prefix)
-    for (int y = 1; y < 4; y++) b.assert_zero(b.mul(b.sub(leaf_inputs_hash.e[y], prev_hash.e[y]), is_leaf_node.t));
-    for (int h = 0; h < 4; h++) prev_hash.e[h] = found[h];
+    for (int h = 0; h < 4; h++) o.found.e[h] = found[h];
+  }
+  b.end_segment();
+  // The chain through the nodes: the first node must hash to the root, every further proof node to the hash found in its parent; and for
+  // the node after the last one, the hash found in the leaf node must carry the leaf-inputs hash (limbs 1..3; the first is partly
+  // overwritten by the trie's nibble prefix).
+  Hash4 prev_hash = t.root_hash;
+  for (int i = 0; i < QPW_MAX_PROOF_LEN; i++) {
+    const NodeOut& o = nodes[i];
+    for (int y = 0; y < 4; y++) b.assert_zero(b.mul(b.sub(o.computed.e[y], prev_hash.e[y]), o.is_proof_node.t));
+    for (int y = 1; y < 4; y++) b.assert_zero(b.mul(b.sub(leaf_inputs_hash.e[y], prev_hash.e[y]), o.is_leaf_node.t));
+    prev_hash = o.found;
   }
 }
 
@@ -233,13 +246,18 @@ const qpgpu_circuit_desc* qpc_circuit_desc(const qpc_circuit* c) { return c ? &c
 size_t qpc_circuit_num_inputs(const qpc_circuit* c) { return c ? c->b.num_inputs() : 0; }
 void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]) { if (!c || !out) return; c->b.row_counts(out); out[6] = (uint32_t)c->b.num_gate_rows(); }
 
-int qpc_generate_witness(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs) { return guard([&]() -> int {
+int qpc_generate_witness_mt(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs, uint32_t threads) { return guard([&]() -> int {
   if (!c || !inputs || !wires || (!public_inputs && c->b.desc().num_public_inputs)) return fail(QPGPU_ERR_ARG, "null argument");
   if (num_inputs != c->b.num_inputs()) return fail(QPGPU_ERR_ARG, "expected " + std::to_string(c->b.num_inputs()) + " input values, got " + std::to_string(num_inputs));
-  const std::string e = c->b.generate(inputs, blinding_key, wires, public_inputs);
+  if (threads == 0) threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const std::string e = c->b.generate(inputs, blinding_key, wires, public_inputs, (int)threads);
   if (!e.empty()) return fail(QPGPU_ERR_WITNESS, e);
   return 0;
 }); }
+int qpc_generate_witness(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs) {
+  return qpc_generate_witness_mt(c, inputs, num_inputs, blinding_key, wires, public_inputs, 0);
+}
+int qpc_circuit_parallel_segments(const qpc_circuit* c) { return c && c->b.parallel_replay() ? 1 : 0; }
 
 int qpw_fill_targets(uint32_t kind, const qpw_circuit_inputs* in, uint64_t* inputs, size_t cap, size_t* len) { return guard([&]() -> int {
   if (!in || !len) return fail(QPGPU_ERR_ARG, "null argument");

@@ -236,6 +236,9 @@ static void eval_gate_constraints(G& g, const Inner& in, const ExtT* consts, con
 void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierDataT& vd) {
   G g{b};
   const int nch = in.nch; const size_t n = size_t(1) << in.log_n;
+  // witness generation replays a proof's transcript / vanishing identity / reduced openings as one stage-1 segment and each of its queries
+  // as a stage-2 segment (builder.h begin_segment): the children of a node, and then all their queries, are independent of each other
+  b.begin_segment(1);
   const Hash4 pi_hash = b.hash_n_to_hash_no_pad(pf.pis);
   // ---- transcript
   ChallengerT ch(b);
@@ -319,6 +322,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
   const int path = in.log_N - in.cap_h;
   const u64 wN = gl_root(in.log_N);
   for (uint32_t qi = 0; qi < in.d.fri_num_queries; qi++) {
+    b.begin_segment(2);
     const QueryT& q = pf.q[qi]; const std::vector<BoolT>& bits = index_bits[qi];
     const std::vector<Target> cap_ind = indicators(b, std::vector<BoolT>(bits.begin() + path, bits.end()));     // cap entry = index >> path (every tree of the query)
     ExtT sum0 = g.cst(0), sum1 = g.cst(0); size_t j = 0;
@@ -365,6 +369,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
     g.assert_eq(fx, old_eval);
     (void)lg;
   }
+  b.end_segment();
 }
 
 } // namespace qpc

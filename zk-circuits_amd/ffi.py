@@ -215,6 +215,8 @@ def circuit_lib():
         L.qpc_circuit_row_counts.restype = None
         L.qpc_circuit_row_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.qpc_generate_witness.argtypes = [ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.c_char_p, u64p, u64p]
+        L.qpc_generate_witness_mt.argtypes = [ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.c_char_p, u64p, u64p, ctypes.c_uint32]
+        L.qpc_circuit_parallel_segments.argtypes = [ctypes.c_void_p]
         L.qpw_fill_targets.argtypes = [ctypes.c_uint32, ctypes.POINTER(WormholeInputsC), u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.qpw_nullifier_from_preimage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_char_p]
         L.qpw_unspendable_account_from_secret.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -335,9 +337,13 @@ class BuiltCircuit:
         circuit_lib().qpc_circuit_row_counts(self.handle, out)
         return dict(zip(self.ROW_KINDS, list(out)))
 
-    def witness(self, inputs, blinding_key=None, out=None):
+    def parallel_segments(self):
+        return bool(circuit_lib().qpc_circuit_parallel_segments(self.handle))
+
+    def witness(self, inputs, blinding_key=None, out=None, threads=0):
         """generate_partial_witness: input-target values -> (wires [W][n], public_inputs). Raises CircuitError (code QPGPU_ERR_WITNESS) when the
-        inputs do not satisfy the circuit. `out` = a (wires, public_inputs) pair from an earlier call to write into (saves the page faults of
+        inputs do not satisfy the circuit. `threads`: host threads for circuits with independent segments (0 = up to 8, 1 = in order).
+        `out` = a (wires, public_inputs) pair from an earlier call to write into (saves the page faults of
         a fresh 17.7 MB matrix)."""
         inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
         if out is not None:
@@ -346,8 +352,8 @@ class BuiltCircuit:
         else:
             wires = np.empty((self.W, self.n), dtype=np.uint64)          # the library zeroes it
             pis = np.zeros(self.desc.num_public_inputs, dtype=np.uint64)
-        circuit_check(circuit_lib().qpc_generate_witness(self.handle, ptr(inputs), len(inputs), None if blinding_key is None else bytes(blinding_key),
-                                                         ptr(wires), ptr(pis)))
+        circuit_check(circuit_lib().qpc_generate_witness_mt(self.handle, ptr(inputs), len(inputs), None if blinding_key is None else bytes(blinding_key),
+                                                            ptr(wires), ptr(pis), threads))
         return wires, pis
 
     def constants_sigmas(self):
