@@ -80,9 +80,12 @@ class WormholeProofAggregator:
         Salts: ChaCha8(salt_key, stream i) for leaf i with a fresh OS-RNG key per call, unless `salt_seed` is given (tests: the
         public test key with stream salt_seed + i, reproducible by the oracle)."""
         cd = self.leaf_circuit_data
+        cores = len(os.sched_getaffinity(0))
+        inner = max(1, min(8, cores // max(1, len(circuit_inputs_list))))  # threads inside one witness when only a few are generated at once
+
         def witness(ci):
             if not isinstance(ci, SyntheticInputs):                       # the reference's CircuitInputs on the built wormhole circuit
-                return cd.generate_witness(ci, os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY)
+                return cd.generate_witness(ci, os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY, threads=inner)
             return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
         if len(circuit_inputs_list) > 1 and not isinstance(circuit_inputs_list[0], SyntheticInputs):
             from concurrent.futures import ThreadPoolExecutor            # witness generation releases the GIL (ctypes): one leaf per host core

@@ -172,13 +172,14 @@ class WormholeCircuitData:
             cls._cache[key] = cls(config, device)
         return cls._cache[key]
 
-    def generate_witness(self, circuit_inputs, blinding_key=None):
-        """generate_partial_witness for a built circuit: the reference's CircuitInputs -> (wires, public_inputs)."""
+    def generate_witness(self, circuit_inputs, blinding_key=None, threads=0):
+        """generate_partial_witness for a built circuit: the reference's CircuitInputs -> (wires, public_inputs). `threads`: host threads
+        for the circuit's independent segments (0 = up to 8)."""
         if self._built is None:
             raise RuntimeError("this circuit was not built from the wormhole circuit definition: commit SyntheticInputs")
         kind = self._built.kind
         targets = circuit_inputs.fill_targets() if kind == ffi.QPC_VOTE else circuit_inputs.fill_targets(kind)
-        return self._built.witness(targets, blinding_key)
+        return self._built.witness(targets, blinding_key, threads=threads)
 
     def witness(self, seed):
         if self._synth is None:
