@@ -58,9 +58,9 @@ void Builder::build() {
   cls_.resize(cells_.size());
   { std::vector<uint32_t> index(cells_.size(), UINT32_MAX); ncls_ = 0;
     for (size_t t = 0; t < cells_.size(); t++) { uint32_t r = find((uint32_t)t); if (index[r] == UINT32_MAX) index[r] = (uint32_t)ncls_++; cls_[t] = index[r]; } }
-  for (size_t t = 0; t < cells_.size(); t++) if (cells_[t].row >= 0) wire_targets_.push_back((Target)t);
-  // column-major order: witness generation writes the wire matrix column by column
-  std::sort(wire_targets_.begin(), wire_targets_.end(), [&](Target a, Target b) { return cells_[a].col != cells_[b].col ? cells_[a].col < cells_[b].col : cells_[a].row < cells_[b].row; });
+  // the cells in use, in column-major order (witness generation writes the wire matrix column by column)
+  { const size_t rows = wire_of_.size() / W;
+    for (int col = 0; col < W; col++) for (size_t row = 0; row < rows; row++) { const Target t = wire_of_[row * W + (size_t)col]; if (t != NO_TARGET) wire_targets_.push_back(t); } }
   fill_dst_.reserve(wire_targets_.size()); fill_cls_.reserve(wire_targets_.size());
   for (Target t : wire_targets_) { fill_dst_.push_back((uint32_t)((size_t)cells_[t].col * n_ + cells_[t].row)); fill_cls_.push_back(cls_[t]); }
 
@@ -180,7 +180,7 @@ void Builder::build() {
     memcpy(d.circuit_digest, acc, sizeof acc); }
   lapb("digest");
   // build-time indexes are not needed to generate witnesses
-  wire_ids_ = {}; arith_cache_ = {}; out_phase_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
+  std::vector<Target>().swap(wire_of_); arith_cache_ = {}; out_phase_ = {}; open_arith_ = {}; consts_ = {}; const_val_ = {}; std::vector<uint32_t>().swap(parent_); std::vector<Target>().swap(wire_targets_);
   built_ = true;
   lapb("free");
 }

@@ -117,7 +117,7 @@ class Builder {
       if (cb && vb == 1) return a;
     }
     if (find(a) > find(b)) std::swap(a, b);                 // the product commutes: one cache entry per unordered pair
-    auto key = std::make_tuple(k0, k1, find(a), find(b), find(c));
+    const ArithKey key{k0, k1, find(a), find(b), find(c)};
     auto hit = arith_cache_.find(key);
     if (hit != arith_cache_.end()) {                        // reuse, unless that would tie two independent segments together (then: a second slot)
       const uint32_t ph = out_phase_[hit->second], me = phase_code();
@@ -229,11 +229,14 @@ class Builder {
   void rec(Op op) { op.stage = cur_stage_; op.seg = cur_seg_; ops_.push_back(op); }
   Target new_target(int32_t row, int16_t col) { cells_.push_back(Cell{row, col}); parent_.push_back((uint32_t)parent_.size()); return (Target)(cells_.size() - 1); }
   Target wire(uint32_t row, int col) {
-    auto key = ((u64)row << 8) | (u64)col;
-    auto it = wire_ids_.find(key); if (it != wire_ids_.end()) return it->second;
-    Target t = new_target((int32_t)row, (int16_t)col); wire_ids_[key] = t; return t;
+    Target& slot = wire_of_[(size_t)row * W + (size_t)col];
+    if (slot == NO_TARGET) slot = new_target((int32_t)row, (int16_t)col);
+    return slot;
   }
-  uint32_t add_row(uint8_t kind, u64 c0, u64 c1) { row_kind_.push_back(kind); row_c0_.push_back(c0); row_c1_.push_back(c1); return (uint32_t)row_kind_.size() - 1; }
+  uint32_t add_row(uint8_t kind, u64 c0, u64 c1) {
+    row_kind_.push_back(kind); row_c0_.push_back(c0); row_c1_.push_back(c1); wire_of_.resize(wire_of_.size() + W, NO_TARGET);
+    return (uint32_t)row_kind_.size() - 1;
+  }
   uint32_t find(uint32_t x) { while (parent_[x] != x) { parent_[x] = parent_[parent_[x]]; x = parent_[x]; } return x; }
   void unite(Target a, Target b) {
     uint32_t ra = find(a), rb = find(b); if (ra == rb) return;
@@ -247,14 +250,17 @@ class Builder {
 
   bool zk_; bool built_ = false;
   std::vector<Cell> cells_; std::vector<uint32_t> parent_;
-  std::unordered_map<u64, Target> wire_ids_;
+  static constexpr Target NO_TARGET = 0xFFFFFFFFu;
+  std::vector<Target> wire_of_;                            // [row][column] -> target of that cell, NO_TARGET until it is used
   std::vector<uint8_t> row_kind_; std::vector<u64> row_c0_, row_c1_;
   std::vector<Op> ops_;
   std::vector<Target> inputs_, public_inputs_;
   std::map<u64, Target> consts_; std::map<uint32_t, u64> const_val_;
   uint32_t const_row_ = 0; int const_slot_ = 0;
   std::map<std::pair<u64, u64>, std::pair<uint32_t, int>> open_arith_;
-  std::map<std::tuple<u64, u64, uint32_t, uint32_t, uint32_t>, Target> arith_cache_;
+  struct ArithKey { u64 k0, k1; uint32_t a, b, c; bool operator==(const ArithKey& o) const { return k0 == o.k0 && k1 == o.k1 && a == o.a && b == o.b && c == o.c; } };
+  struct ArithHash { size_t operator()(const ArithKey& k) const { u64 h = k.k0 * 0x9E3779B97F4A7C15ULL ^ k.k1 * 0xC2B2AE3D27D4EB4FULL; h ^= ((u64)k.a << 32 | k.b) * 0x165667B19E3779F9ULL; h ^= (u64)k.c * 0x27D4EB2F165667C5ULL; return (size_t)(h ^ (h >> 29)); } };
+  std::unordered_map<ArithKey, Target, ArithHash> arith_cache_;
   Target zero_, one_;
   uint8_t cur_stage_ = 0; uint32_t cur_seg_ = 0, seg_count_[3] = {0, 0, 0}; bool seen_segment_ = false;
   std::unordered_map<Target, uint32_t> out_phase_;         // arithmetic outputs: where they were recorded (0 leading, stage << 28 | 1 + segment, ~0 trailing)
