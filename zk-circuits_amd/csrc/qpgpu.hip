@@ -49,6 +49,7 @@ void options_refresh_from_env() {
   o.pair_leaves = geti("QPGPU_PAIR_LEAVES", o.pair_leaves); o.pair_max = geti("QPGPU_PAIR_MAX", o.pair_max); o.coop_max = geti("QPGPU_COOP_MAX", o.coop_max);
   o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
+  o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift);
   const int nxt = 1 - g_opts_cur.load(std::memory_order_relaxed);
   g_opts[nxt] = o; g_opts_cur.store(nxt, std::memory_order_release);
 }
@@ -746,6 +747,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
     // first launch = the expected number of candidates (2^pow_bits: 63 % of proofs stop there), then doubling spans; the smallest valid
     // witness wins whatever the span schedule (atomicMin over a range that is complete before the next one starts)
     u64 base = 0, span = 1ULL << (d.fri_pow_bits < 12 ? 12 : (d.fri_pow_bits > 22 ? 22 : d.fri_pow_bits));
+    { const int sh = qp::opts().pow_first_shift; if (sh > 0 && sh <= 4) span <<= sh; }
     for (int iter = 0; iter < 24 && pow_witness == none; iter++) {
       { ProfScope ps(w, s, PF_POW, 0.0); pow_grind(sp, pos, base, span, (int)d.fri_pow_bits, w->pow_result, s); }
       { int rc_ = fetch_to_host(w, s, w->pow_result, 1); if (rc_) return rc_; }
