@@ -8,9 +8,10 @@ pkg = importlib.import_module("zk-circuits_amd")
 
 
 def main(out_path="proof_from_bins.hex"):
-    # Create inputs. In practice, each input would be gathered from the real node.
+    # The inputs of the reference's example (a deployment reads them from a chain node): no storage-proof nodes, so the root hash is the
+    # leaf-inputs hash itself.
     funding_account = pkg.BytesDigest(bytes([226, 124, 203, 9, 80, 60, 124, 205, 165, 5, 178, 216, 195, 15, 149, 38, 116, 1, 238, 133,
-                                             181, 154, 106, 17, 41, 228, 118, 179, 82, 141, 225, 76]))         # Alice's dev account
+                                             181, 154, 106, 17, 41, 228, 118, 179, 82, 141, 225, 76]))         # the funding account the reference's example uses
     secret = bytes([1] * 32)
     unspendable_account = pkg.unspendable_account_from_secret(secret)
     funding_amount = 1_000_000_000_000

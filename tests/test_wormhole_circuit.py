@@ -295,7 +295,7 @@ def test_the_reference_example_inputs_with_an_empty_storage_proof(circuits):
     i = 0 = proof_len), secret [1; 32], transfer count 0, exit account id 8226349481601990196."""
     c, oc = circuits(QPC_WORMHOLE)
     secret = bytes([1] * 32)
-    funding = pkg.BytesDigest(th.DEFAULT_FUNDING_ACCOUNT)                         # "Alice's dev account": the same bytes as the test helpers'
+    funding = pkg.BytesDigest(th.DEFAULT_FUNDING_ACCOUNT)                         # the example's funding account: the same bytes as the test helpers'
     unspendable = pkg.unspendable_account_from_secret(secret)
     amount = 1_000_000_000_000
     leaf_felts = [0, 0] + funding.to_felts() + unspendable.to_felts() + [(amount >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)]
