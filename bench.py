@@ -414,6 +414,35 @@ def main():
         except Exception as e:                                  # never let the extra measurement take the headline down
             tree = {"error": repr(e)[:300]}
 
+    # ---- extra, NOT the headline: the reference's verifier bench (wormhole/verifier/benches/verifier.rs:13-32, `verifier_verify_proof`): build
+    # the verifier from common.bin / verifier.bin and verify the reference's golden proof (wormhole/bench-data; the repo keeps byte-identical
+    # copies as test fixtures under tests/golden). One proof per call as the reference's loop does, and 64 copies as one batch.
+    golden_verify = None
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if rank == 0 and args.batch == 1 and all(os.path.exists(os.path.join(gdir, f)) for f in ("common.bin", "verifier.bin", "proof.bin")):
+        try:
+            rd = lambda f: open(os.path.join(gdir, f), "rb").read()
+            common_b, verifier_b, proof_b = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
+            vo = verifier_b[:len(verifier_b) - len(common_b)] if verifier_b.endswith(common_b) and len(verifier_b) > len(common_b) else verifier_b
+            t0_ = time.perf_counter()
+            shape = H.ReferenceCircuitShape(common_b, vo); gv = H.GpuVerifier(shape.desc, shape.constants_sigmas_cap, device=local_rank)
+            setup_ms = (time.perf_counter() - t0_) * 1e3
+            ok1 = gv.verify(proof_b) is None
+            reps_ = 20; t0_ = time.perf_counter()
+            for _ in range(reps_):
+                gv.verify(proof_b)
+            one_ms = (time.perf_counter() - t0_) / reps_ * 1e3
+            okb, _ = gv.verify_batch([proof_b] * 64); t0_ = time.perf_counter()
+            okb, _ = gv.verify_batch([proof_b] * 64)
+            b64_ms = (time.perf_counter() - t0_) * 1e3
+            bad = bytearray(proof_b); bad[-1] ^= 1
+            golden_verify = {"proof": "wormhole/bench-data/proof.bin with common.bin / verifier.bin (the reference's golden proof)", "accepted": bool(ok1 and all(okb)),
+                             "forged_public_input_rejected": bool(gv.verify(bytes(bad)) is not None), "verifier_setup_ms": round(setup_ms, 2),
+                             "verify_ms": round(one_ms, 3), "batch64_ms": round(b64_ms, 3), "batch64_proofs_per_s": round(64 / (b64_ms * 1e-3), 1)}
+            gv.close()
+        except Exception as e:
+            golden_verify = {"error": repr(e)[:200]}
+
     # Poseidon throughput of the dominant kernel against the VALU issue ceiling. Both ceilings come from a committed
     # file: the first-principles bound (static ISA instruction counts x 2 or 4 issue cycles, tools/poseidon_issue_bound.py) and the
     # measured saturation of the same kernel body (tools/permute_rate.py on MI355X).
@@ -463,7 +492,7 @@ def main():
                    "zero_knowledge": bool(sc.desc.zero_knowledge), "proof_bytes": gc.proof_size,
                    "host_cpus": pinned, "parallelism": "independent proofs, one process per GPU" + ("; RCCL all_gather of proof blobs after the steps" if world > 1 else "")},
         "ms_per_proof": round(dt / (args.steps * args.batch) * 1e3, 4),
-        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "aggregation_tree": tree, "wormhole_circuit": real, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "roofline": roofline, "whole_proof_hbm": whole, "valu_roofline": valu, "pipelined": pipelined, "aggregation_tree": tree, "wormhole_circuit": real, "reference_golden_proof_verify": golden_verify, "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement ("port"), OpenMP on the host cores, bounded sample

@@ -148,3 +148,24 @@ def test_lookup_gates_are_refused():
             GpuVerifier(bad, gc.cap())
     finally:
         gc.close()
+
+
+def test_both_forms_of_the_opening_kernel_agree(monkeypatch):
+    """The verifier checks Merkle openings 16 lanes per opening for small batches and one lane per opening for large ones
+    (QPGPU_VERIFY_COOP_MAX): both forms accept the reference's golden proof and a batch of device-made proofs, and reject the same tampering."""
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rd = lambda f: open(os.path.join(g, f), "rb").read()
+    common, vb, proof = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
+    vo = vb[:len(vb) - len(common)] if vb.endswith(common) and len(vb) > len(common) else vb
+    bad_sib = bytearray(proof); bad_sib[3 * 512 + 16 * 257 + 3 * 512 + 8 * 84 + 1 + 5] ^= 1        # a sibling digest of the first query's first opening
+    bad_row = bytearray(proof); bad_row[3 * 512 + 16 * 257 + 3 * 512 + 3] ^= 1                      # a row element of it
+    verdicts = {}
+    for mode in ("16384", "0"):
+        monkeypatch.setenv("QPGPU_VERIFY_COOP_MAX", mode)
+        shape = ReferenceCircuitShape(common, vo)
+        v = GpuVerifier(shape.desc, shape.constants_sigmas_cap)
+        ok, reasons = v.verify_batch([proof, bytes(bad_sib), proof, bytes(bad_row)] * 3)
+        verdicts[mode] = ok
+        assert ok == [True, False, True, False] * 3, (mode, reasons)
+        v.close()
+    assert verdicts["16384"] == verdicts["0"]

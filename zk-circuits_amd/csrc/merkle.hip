@@ -378,9 +378,43 @@ __global__ void __launch_bounds__(256) k_verify_paths(const u64* rows, int width
   for (int k = 0; k < 4; k++) same = same && st[k] == cap[k];
   ok[p] = same ? 1u : 0u;
 }
+// The same with 16 lanes per opening (one state element per lane, coop_permute): an opening is a chain of 13-31 dependent permutations, and
+// with the openings of a few proofs only (28 per proof and tree) a per-lane permutation (~59 us alone on a SIMD) makes the launch pure latency.
+__global__ void __launch_bounds__(64) k_verify_paths_coop(const u64* rows, int width, const u64* sibs, int depth, const u32* idx, const u64* caps,
+                                                          const u32* cap_of, int cap_h, size_t np, u32* ok) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ u64 xch[4][24];
+  const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
+  const size_t p = (size_t)blockIdx.x * 4 + g, pp = p < np ? p : np - 1;     // idle groups repeat the last opening (all 64 lanes must take part)
+  CoopCtx cx; coop_init(cx, i);
+  const u64* row = rows + pp * (size_t)width;
+  u64 x = 0;
+  if (width <= 4) { if (i < width) x = row[i]; }
+  else {
+    for (int off = 0; off < width; off += 8) {
+      if (i < 8 && off + i < width) x = row[off + i];          // overwrite mode: the other lanes keep their state
+      x = coop_permute(x, i, cx, xch[g]);
+    }
+  }
+  u32 index = idx[pp];
+  const u64* sb = sibs + pp * (size_t)depth * 4;
+  for (int l = 0; l < depth; l++, sb += 4) {
+    const bool right = index & 1;                              // this node is the right child: the sibling goes first
+    const u64 below = __shfl(x, (int)threadIdx.x - 4);         // lanes 4..7 see the running digest of lanes 0..3
+    u64 nx = 0;
+    if (i < 4) nx = right ? sb[i] : x;
+    else if (i < 8) nx = right ? below : sb[i - 4];
+    x = coop_permute(nx, i, cx, xch[g]);
+    index >>= 1;
+  }
+  const u64* cap = caps + (((size_t)(cap_of ? cap_of[pp] : 0)) << (cap_h + 2)) + (size_t)index * 4;
+  const unsigned long long agree = __ballot(i >= 4 || x == cap[i & 3]);
+  if (p < np && i == 0) ok[p] = ((agree >> (16 * g)) & 0xFFFFull) == 0xFFFFull ? 1u : 0u;
+}
 void verify_paths(const u64* rows, int width, const u64* sibs, int depth, const u32* idx, const u64* caps, const u32* cap_of, int cap_h,
                   size_t num_paths, u32* ok, hipStream_t s) {
   if (!num_paths) return;
+  if ((long long)num_paths <= (long long)opts().verify_coop_max) { hipLaunchKernelGGL(k_verify_paths_coop, dim3((unsigned)((num_paths + 3) / 4)), dim3(64), 0, s, rows, width, sibs, depth, idx, caps, cap_of, cap_h, num_paths, ok); return; }
   hipLaunchKernelGGL(k_verify_paths, dim3((unsigned)((num_paths + 255) / 256)), dim3(256), 0, s, rows, width, sibs, depth, idx, caps, cap_of, cap_h, num_paths, ok);
 }
 

@@ -50,6 +50,7 @@ void options_refresh_from_env() {
   o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
   o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift);
+  o.verify_coop_max = geti("QPGPU_VERIFY_COOP_MAX", o.verify_coop_max);
   const int nxt = 1 - g_opts_cur.load(std::memory_order_relaxed);
   g_opts[nxt] = o; g_opts_cur.store(nxt, std::memory_order_release);
 }

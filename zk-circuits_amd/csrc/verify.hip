@@ -21,6 +21,9 @@
 #include <thread>
 #include <atomic>
 #include <mutex>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -37,6 +40,8 @@ struct qpgpu_verifier {
   u64* d_cap = nullptr;
   std::mutex mu;      // one batch at a time per handle (the staging buffers below are reused)
   void* d_stage = nullptr; size_t d_stage_bytes = 0;
+  u64* h_stage = nullptr; size_t h_stage_words = 0;        // pinned host staging buffer of the openings
+  hipStream_t streams[4 + MAX_FRI_LAYERS] = {};            // one per tree kind (their openings are checked concurrently)
 };
 
 namespace {
@@ -477,6 +482,8 @@ void qpgpu_verifier_destroy(qpgpu_verifier* v) {
   (void)hipSetDevice(v->device);
   if (v->d_cap) (void)hipFree(v->d_cap);
   if (v->d_stage) (void)hipFree(v->d_stage);
+  if (v->h_stage) (void)hipHostFree(v->h_stage);
+  for (auto& st : v->streams) if (st) (void)hipStreamDestroy(st);
   delete v;
 }
 
@@ -488,6 +495,8 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
   if (proof_stride < proof_len) return set_err(QPGPU_ERR_ARG, "proof_stride smaller than proof_len");
   std::lock_guard<std::mutex> lk(v->mu);
   std::vector<ProofWork> work(count);
+  static const bool vt = getenv("QPGPU_VERIFY_TIMING") != nullptr; auto vt0 = std::chrono::steady_clock::now();
+  auto vlap = [&](const char* what) { if (vt) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  verify %-8s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - vt0).count()); vt0 = t; } };
   // ---- host pass: transcript, PoW, vanishing identity, FRI arithmetic (worker threads over proofs)
   {
     std::atomic<size_t> next(0);
@@ -504,45 +513,85 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
     std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
     body(); for (auto& t : th) t.join();
   }
-  // ---- device pass: all Merkle openings of the proofs that survived, one launch per tree kind
+  vlap("host");
+  // ---- device pass: all Merkle openings of the proofs that survived. One staging buffer for every tree kind, one upload, one launch per
+  // tree kind (a wave's lanes then run the same sponge length and path depth) on a stream of its own — the kinds are independent, and with few
+  // proofs each launch is a handful of lanes walking 13-31 dependent permutations, so they overlap instead of queueing — one download.
   V_TRY(hipSetDevice(v->device));
   const int kinds = 4 + v->nlayers;
   const size_t widths[4] = {(size_t)v->S, (size_t)v->W + v->salt, (size_t)v->Zp + v->salt, (size_t)v->Q + v->salt};
-  std::vector<size_t> owner;                                       // path -> proof, per kind (rebuilt per kind)
+  const size_t capw = size_t(4) << v->cap_h;
+  struct Kind { size_t width = 0, depth = 0, np = 0, rows_off = 0, sibs_off = 0, caps_off = 0, idx_off = 0, capof_off = 0, ok_off = 0, cap_bytes_off = 0; bool shared_cap = false; std::vector<size_t> owner; };
+  std::vector<Kind> K((size_t)kinds);
+  size_t live = 0; for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) live++;
+  size_t words = 0, ok_words = 0;                                  // 8-byte words of the input part; u32 slots of the result part
   for (int k = 0; k < kinds; k++) {
-    size_t width, depth; const u64* caps_dev = nullptr; size_t cap_off_bytes = 0; bool shared_cap = false;
-    if (k < 4) { width = widths[k]; depth = v->log_N - v->cap_h; shared_cap = k == 0; cap_off_bytes = (size_t)(k - 1) * v->lay.cap_bytes; }
-    else { const int l = k - 4; int lg = v->log_N; for (int i = 0; i < l; i++) lg -= v->arity[i]; width = (size_t)2 << v->arity[l]; depth = lg - v->arity[l] - v->cap_h; cap_off_bytes = v->lay.fri_caps_off + (size_t)l * v->lay.cap_bytes; }
-    owner.clear(); size_t live = 0;
-    for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) { live++; for (size_t j = 0; j < work[i].paths[k].size(); j++) owner.push_back(i); }
-    const size_t np = owner.size(); if (!np) continue;
-    // staging layout: rows [np][width] | sibs [np][depth][4] | caps [live][capn][4] (or the verifier's own cap) | idx [np] u32 | cap_of [np] u32 | ok [np] u32
-    const size_t capw = size_t(4) << v->cap_h;
-    const size_t rows_w = np * width, sibs_w = np * depth * 4, caps_w = shared_cap ? 0 : live * capw;
-    const size_t bytes = (rows_w + sibs_w + caps_w) * 8 + np * 12 + 64;
-    std::vector<u64> host((bytes + 7) / 8);
-    u64* h_rows = host.data(); u64* h_sibs = h_rows + rows_w; u64* h_caps = h_sibs + sibs_w;
-    u32* h_idx = (u32*)(h_caps + caps_w); u32* h_capof = h_idx + np;
-    { size_t p = 0, live_i = 0;
-      for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) {
-        if (!shared_cap) for (size_t c = 0; c < capw; c++) h_caps[live_i * capw + c] = rd64(proofs + i * proof_stride + cap_off_bytes + 8 * c);
-        for (const PathRef& pr : work[i].paths[k]) {
-          for (size_t c = 0; c < width; c++) h_rows[p * width + c] = rd64(pr.row + 8 * c);
-          for (size_t c = 0; c < depth * 4; c++) h_sibs[p * depth * 4 + c] = rd64(pr.sibs + 8 * c);
-          h_idx[p] = pr.index; h_capof[p] = (u32)live_i; p++;
+    Kind& kd = K[(size_t)k];
+    if (k < 4) { kd.width = widths[k]; kd.depth = v->log_N - v->cap_h; kd.shared_cap = k == 0; kd.cap_bytes_off = (size_t)(k - 1) * v->lay.cap_bytes; }
+    else { const int l = k - 4; int lg = v->log_N; for (int i = 0; i < l; i++) lg -= v->arity[i]; kd.width = (size_t)2 << v->arity[l]; kd.depth = lg - v->arity[l] - v->cap_h; kd.cap_bytes_off = v->lay.fri_caps_off + (size_t)l * v->lay.cap_bytes; }
+    for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) for (size_t j = 0; j < work[i].paths[k].size(); j++) kd.owner.push_back(i);
+    kd.np = kd.owner.size(); if (!kd.np) continue;
+    kd.rows_off = words; words += kd.np * kd.width;
+    kd.sibs_off = words; words += kd.np * kd.depth * 4;
+    kd.caps_off = words; words += kd.shared_cap ? 0 : live * capw;
+    kd.idx_off = words; words += (kd.np + 1) / 2;                  // u32 arrays, padded to whole words
+    kd.capof_off = words; words += (kd.np + 1) / 2;
+    kd.ok_off = ok_words; ok_words += kd.np;
+  }
+  if (ok_words) {
+    // pinned host staging (kept with the handle): no page faults of a fresh buffer per batch, DMA straight from it
+    if (v->h_stage_words < words) { if (v->h_stage) (void)hipHostFree(v->h_stage); v->h_stage = nullptr; v->h_stage_words = 0;
+      V_TRY(hipHostMalloc((void**)&v->h_stage, (words + words / 4) * 8, hipHostMallocDefault)); v->h_stage_words = words + words / 4; }
+    u64* const host = v->h_stage;
+    std::vector<size_t> live_of(count, (size_t)-1); { size_t li = 0; for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) live_of[i] = li++; }
+    std::vector<std::vector<size_t>> first(kinds);                // per kind: index of each proof's first opening
+    for (int k = 0; k < kinds; k++) { first[k].assign(count, 0); size_t p = 0; for (size_t i = 0; i < count; i++) if (work[i].reason.empty()) { first[k][i] = p; p += work[i].paths[k].size(); } }
+    { std::atomic<size_t> next(0);                                 // proofs over host threads: each writes its own slices of every kind
+      auto body = [&]() {
+        for (;;) {
+          const size_t i = next.fetch_add(1); if (i >= count) break;
+          if (!work[i].reason.empty()) continue;
+          for (int k = 0; k < kinds; k++) {
+            const Kind& kd = K[(size_t)k]; if (!kd.np) continue;
+            u64* h_rows = host + kd.rows_off; u64* h_sibs = host + kd.sibs_off; u64* h_caps = host + kd.caps_off;
+            u32* h_idx = (u32*)(host + kd.idx_off); u32* h_capof = (u32*)(host + kd.capof_off);
+            const size_t live_i = live_of[i];
+            if (!kd.shared_cap) for (size_t c = 0; c < capw; c++) h_caps[live_i * capw + c] = rd64(proofs + i * proof_stride + kd.cap_bytes_off + 8 * c);
+            size_t p = first[k][i];
+            for (const PathRef& pr : work[i].paths[k]) {
+              for (size_t c = 0; c < kd.width; c++) h_rows[p * kd.width + c] = rd64(pr.row + 8 * c);
+              for (size_t c = 0; c < kd.depth * 4; c++) h_sibs[p * kd.depth * 4 + c] = rd64(pr.sibs + 8 * c);
+              h_idx[p] = pr.index; h_capof[p] = (u32)live_i; p++;
+            }
+          }
         }
-        live_i++;
-      } }
+      };
+      size_t nthreads = std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
+      std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
+      body(); for (auto& t : th) t.join(); }
+    const size_t bytes = words * 8 + ok_words * 4 + 64;
     if (v->d_stage_bytes < bytes) { if (v->d_stage) (void)hipFree(v->d_stage); v->d_stage = nullptr; v->d_stage_bytes = 0; V_TRY(hipMalloc(&v->d_stage, bytes + bytes / 4)); v->d_stage_bytes = bytes + bytes / 4; }
-    V_TRY(hipMemcpy(v->d_stage, host.data(), (rows_w + sibs_w + caps_w) * 8 + np * 8, hipMemcpyHostToDevice));
-    u64* d_rows = (u64*)v->d_stage; u64* d_sibs = d_rows + rows_w; u64* d_caps = d_sibs + sibs_w; u32* d_idx = (u32*)(d_caps + caps_w); u32* d_capof = d_idx + np; u32* d_ok = d_capof + np;
-    caps_dev = shared_cap ? v->d_cap : d_caps;
-    verify_paths(d_rows, (int)width, d_sibs, (int)depth, d_idx, caps_dev, shared_cap ? nullptr : d_capof, v->cap_h, np, d_ok, 0);
+    for (int k = 0; k < kinds; k++) if (!v->streams[k]) V_TRY(hipStreamCreateWithFlags(&v->streams[k], hipStreamNonBlocking));
+    vlap("stage");
+    V_TRY(hipMemcpy(v->d_stage, host, words * 8, hipMemcpyHostToDevice));
+    vlap("upload");
+    u64* d_base = (u64*)v->d_stage; u32* d_ok = (u32*)(d_base + words);
+    for (int k = 0; k < kinds; k++) {
+      const Kind& kd = K[(size_t)k]; if (!kd.np) continue;
+      verify_paths(d_base + kd.rows_off, (int)kd.width, d_base + kd.sibs_off, (int)kd.depth, (const u32*)(d_base + kd.idx_off), kd.shared_cap ? v->d_cap : d_base + kd.caps_off,
+                   kd.shared_cap ? nullptr : (const u32*)(d_base + kd.capof_off), v->cap_h, kd.np, d_ok + kd.ok_off, v->streams[k]);
+    }
     V_TRY(hipGetLastError());
-    std::vector<u32> ok(np);
-    V_TRY(hipMemcpy(ok.data(), d_ok, np * 4, hipMemcpyDeviceToHost));
-    for (size_t p = 0; p < np; p++) if (!ok[p] && work[owner[p]].reason.empty())
-      work[owner[p]].reason = (k < 4 ? "initial Merkle opening (oracle " + std::to_string(k) + ")" : "FRI Merkle opening (layer " + std::to_string(k - 4) + ")");
+    for (int k = 0; k < kinds; k++) if (K[(size_t)k].np) V_TRY(hipStreamSynchronize(v->streams[k]));
+    vlap("kernels");
+    std::vector<u32> ok(ok_words);
+    V_TRY(hipMemcpy(ok.data(), d_ok, ok_words * 4, hipMemcpyDeviceToHost));
+    vlap("download");
+    for (int k = 0; k < kinds; k++) {
+      const Kind& kd = K[(size_t)k];
+      for (size_t p = 0; p < kd.np; p++) if (!ok[kd.ok_off + p] && work[kd.owner[p]].reason.empty())
+        work[kd.owner[p]].reason = (k < 4 ? "initial Merkle opening (oracle " + std::to_string(k) + ")" : "FRI Merkle opening (layer " + std::to_string(k - 4) + ")");
+    }
   }
   int rc = 0;
   for (size_t i = 0; i < count; i++) {
