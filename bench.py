@@ -72,8 +72,11 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra (untimed-headline) stream-pipelined throughput measurement")
     ap.add_argument("--cpu-proofs", type=int, default=8)
     ap.add_argument("--no-tree", action="store_true", help="skip the extra aggregation-tree measurement (BASELINE configs[2]/[3] flavour)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no pipelined / tree / real-circuit / golden-verify extras and no CPU baseline (profiler runs: one workload per trace)")
     ap.add_argument("--no-real-circuit", action="store_true", help="skip the extra line on the wormhole circuit built by libqpcircuit (the reference's test inputs)")
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_pipelined = args.no_tree = args.no_real_circuit = args.no_cpu_baseline = True
 
     import importlib
     import numpy as np
@@ -419,7 +422,7 @@ def main():
     # copies as test fixtures under tests/golden). One proof per call as the reference's loop does, and 64 copies as one batch.
     golden_verify = None
     gdir = os.path.join(ROOT, "tests", "golden")
-    if rank == 0 and args.batch == 1 and all(os.path.exists(os.path.join(gdir, f)) for f in ("common.bin", "verifier.bin", "proof.bin")):
+    if rank == 0 and args.batch == 1 and not args.no_extras and all(os.path.exists(os.path.join(gdir, f)) for f in ("common.bin", "verifier.bin", "proof.bin")):
         try:
             rd = lambda f: open(os.path.join(gdir, f), "rb").read()
             common_b, verifier_b, proof_b = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")

@@ -43,7 +43,7 @@ def main():
     calib_w, calib_n = 139, 1 << 17
     calib_cmd = ["python3", "-c", "import ctypes; L=ctypes.CDLL('zk-circuits_amd/libqpgpu.so'); L.qpgpu_test_calib_colsum.argtypes=[ctypes.c_int,ctypes.c_size_t,ctypes.c_int]; L.qpgpu_test_calib_colsum(%d,%d,5)" % (calib_w, calib_n)]
     # one workload per profiler run: no aggregation-tree / pipelined extras, so every counter row belongs to this preset's proofs
-    bench_cmd = ["python3", "bench.py", "--preset", args.preset, "--steps", "3" if args.preset == "V" else "4", "--warmup", "1", "--no-cpu-baseline",
+    bench_cmd = ["python3", "bench.py", "--preset", args.preset, "--steps", "3" if args.preset == "V" else "4", "--warmup", "1", "--no-extras",
                  "--no-tree", "--no-pipelined"] + (["--batch", str(args.batch)] if args.batch > 1 else [])
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -9,7 +9,7 @@ def run(counters, tag):
     shutil.rmtree(os.path.join(ROOT, out), ignore_errors=True)          # one workload per directory
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
-           "python3", "bench.py", "--preset", ARGS.preset, "--steps", "2" if ARGS.preset == "V" else "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipelined", "--no-tree"]
+           "python3", "bench.py", "--preset", ARGS.preset, "--steps", "2" if ARGS.preset == "V" else "3", "--warmup", "1", "--no-extras"]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(env, QP_BENCH_SETTLE_S="0"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     if r.returncode != 0:
         print(tag, "failed:", r.stderr.decode()[-300:]); return {}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-config rocprofv3 summaries (run on the GPU box from the repo root: bash tools/profile_round2.sh). One config per profiler run, extras
-# off (--no-tree --no-pipelined --no-cpu-baseline), so that every kernel_stats.csv describes exactly one workload:
+# off (--no-extras), so that every kernel_stats.csv describes exactly one workload:
 #   W  = BASELINE configs[1] (single proof of the wormhole circuit, zk, 2^14; the default)   B  = the same shape, synthetic gate contents     A = non-zk leaf 2^13      V = configs[4] (2^20 rows)      B64 = configs[2] (batch of 64)
 # Outputs under gpurun_out/r02prof/: <cfg>_kernel_stats.csv, <cfg>_bench.json, timeline_B.txt; copy what is to be judged into profiles/.
 set -e
@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {   # name, bench args...
   name=$1; shift
   rm -rf /tmp/pf_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$name -o $name -- python3 $R/bench.py --no-tree --no-pipelined --no-cpu-baseline "$@" > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$name -o $name -- python3 $R/bench.py --no-extras "$@" > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err
   cp $(find /tmp/pf_$name -name "${name}_kernel_stats.csv" | head -1) $OUT/${name}_kernel_stats.csv
   echo "profiled $name"
 }
