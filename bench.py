@@ -404,7 +404,7 @@ def main():
             # the aggregator's intake check: all 64 leaf proofs through the product's batch verifier (device Merkle openings + host algebra)
             try:
                 ver = H.GpuVerifier(sc.desc, gc.cap(), device=local_rank)
-                ver.verify_batch(leaf_proofs[:8])                                       # warm
+                ver.verify_batch(leaf_proofs)                                           # warm (staging buffers sized for the batch)
                 torch.cuda.synchronize(); tv = time.perf_counter()
                 okv, _ = ver.verify_batch(leaf_proofs)
                 tv = time.perf_counter() - tv
