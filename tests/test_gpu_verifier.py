@@ -169,3 +169,31 @@ def test_both_forms_of_the_opening_kernel_agree(monkeypatch):
         assert ok == [True, False, True, False] * 3, (mode, reasons)
         v.close()
     assert verdicts["16384"] == verdicts["0"]
+
+
+from test_oracle_prover import SHAPES
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+@pytest.mark.parametrize("coop", ["16384", "0"])
+def test_varied_shapes_through_both_opening_kernels(monkeypatch, shape, coop):
+    """FRI arities 1..4 (4-felt FRI leaves are not hashed), cap heights 0..4, a last layer whose tree is its cap (empty paths), no FRI layers,
+    zk: the product verifier accepts device proofs of every shape and rejects a flipped Merkle sibling and a flipped public input, with the
+    16-lane and the per-lane opening kernels."""
+    monkeypatch.setenv("QPGPU_VERIFY_COOP_MAX", coop)
+    sc = SynthCircuit("T", **shape); gc = GpuCircuit(sc.desc); oc = OracleCircuit(sc.desc)
+    try:
+        w, p = sc.witness(5)
+        proof = gc.prove(w, p, salt_seed=5)
+        v = GpuVerifier(sc.desc, gc.cap())
+        bad_pi = bytearray(proof); bad_pi[-1] ^= 1
+        d = sc.desc
+        S = d.num_constants + d.num_routed; nop = S + d.num_wires + 4 + 2 * d.num_partial_products + 16
+        queries_off = (3 + d.fri_num_layers) * (32 << d.fri_cap_height) + 16 * nop
+        bad_row = bytearray(proof); bad_row[queries_off + 2] ^= 1                    # first element of the first query's constants/sigmas row
+        ok, reasons = v.verify_batch([proof, bytes(bad_pi), bytes(bad_row), proof])
+        assert ok == [True, False, False, True], reasons
+        assert [oc.verify(x) is None for x in (proof, bytes(bad_pi), bytes(bad_row))] == [True, False, False]
+        v.close()
+    finally:
+        gc.close()
