@@ -10,7 +10,8 @@
  *                         VoteCircuitData::circuit (voting/src/lib.rs:123-197), on this repo's own builder (zk-circuits_amd/circuit/builder.h);
  *   3. witness generation = qp-plonky2's generate_partial_witness: input targets -> full wire matrix + public inputs; inputs that do not
  *                         satisfy the statement fail here, as in the reference ("set twice with different values").
- * The statement, the public inputs and their order are the reference's; rows, copy constraints and the circuit digest are this
+ * The statement, the public inputs and their order are the reference's, and so is the whole CommonCircuitData (the zk wormhole circuit's
+ * common.bin is byte-identical to wormhole/bench-data/common.bin); rows, copy constraints and the circuit digest are this
  * builder's own ("parity unpinned": qp-plonky2's CircuitBuilder is not on disk), so proofs verify against the verifier data of the
  * circuit built here, not against the reference's verifier.bin.
  */

@@ -329,3 +329,19 @@ def test_builder_fuzz_random_programs(seed):
         assert list(p2) != list(expected)
     except CircuitError:
         pass
+
+
+def test_built_wormhole_circuit_has_the_reference_common_circuit_data(circuits):
+    """The CommonCircuitData of the wormhole circuit built here under standard_recursion_zk_config, written in plonky2's byte format by the
+    product's writer, is byte-identical to the reference's wormhole/bench-data/common.bin (1,045 bytes): circuit config, FRI parameters and
+    reduction arities, degree 2^14, the gate list with its parameters in upstream's order, selector indices and groups, quotient degree
+    factor, 123 gate constraints, 4 constant columns, 16 public inputs, the k_i coset shifts, 9 partial products. What common data does not
+    hold — rows, sigma, constants — stays this builder's own."""
+    ffi = pkg.ffi
+    ref = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "common.bin"), "rb").read()
+    c, _ = circuits(QPC_WORMHOLE, True)
+    assert ffi.write_common(c.desc) == ref
+    nz, _ = circuits(QPC_WORMHOLE, False)
+    assert ffi.write_common(nz.desc) != ref                                       # the non-zk circuit: degree 2^13, two reductions, no hiding
+    shape = ReferenceCircuitShape(ffi.write_common(nz.desc), ffi.write_verifier_only(np.zeros((16, 4), dtype=np.uint64), 4, [0, 0, 0, 0]))
+    assert shape.desc.degree_bits == 13 and shape.desc.zero_knowledge == 0 and shape.desc.fri_num_layers == 2
