@@ -345,3 +345,15 @@ def test_built_wormhole_circuit_has_the_reference_common_circuit_data(circuits):
     assert ffi.write_common(nz.desc) != ref                                       # the non-zk circuit: degree 2^13, two reductions, no hiding
     shape = ReferenceCircuitShape(ffi.write_common(nz.desc), ffi.write_verifier_only(np.zeros((16, 4), dtype=np.uint64), 4, [0, 0, 0, 0]))
     assert shape.desc.degree_bits == 13 and shape.desc.zero_knowledge == 0 and shape.desc.fri_num_layers == 2
+
+
+@pytest.mark.parametrize("name", ["dummy_proof.bin", "dummy_proof_zk.bin"])
+def test_public_inputs_equal_those_of_the_reference_dummy_proofs(circuits, name):
+    """wormhole/aggregator/data/dummy_proof{,_zk}.bin are proofs the reference's prover made for CircuitInputs::test_inputs()
+    (prover_tests.rs:56-82): their 16 public-input felts are the ones this circuit's witness generation produces from the same inputs, and a
+    proof of the non-zk circuit built here has their length."""
+    blob = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), "rb").read()
+    c, _ = circuits(QPC_WORMHOLE)
+    _, p = c.witness(th.circuit_test_inputs().fill_targets())
+    assert list(np.frombuffer(blob[-128:], dtype="<u8")) == [int(x) for x in p]
+    assert int.from_bytes(blob[-136:-128], "little") == 16 and len(blob) == pkg.ffi.proof_size_of(c.desc)
