@@ -3,7 +3,7 @@ checker: aggregate_chunk of the reference (wormhole/aggregator/src/circuits/tree
 recursive_aggregation_tree, pair_aggregation, public_inputs_are_aggregated) on small inner circuits so that the oracle prover finishes in
 seconds. The in-circuit verifier is this repo's own restatement of its host verifier (qp-plonky2's is not on disk): what is checked is that
 a node circuit's witness exists exactly when every child proof verifies, that the node's proof verifies, and that levels compose."""
-import importlib
+import importlib, os
 import numpy as np
 import pytest
 from harness import *
@@ -120,3 +120,25 @@ def test_synthetic_leaf_shape_aggregates_too():
     node = BuiltCircuit.aggregation(sc.desc, 2); on = OracleCircuit(node.desc)
     w1, p1 = node.witness(node.aggregation_targets(oc.cap(), sc.desc.circuit_digest, [leaf, leaf]))
     assert check_witness(on, w1, p1) is None
+
+
+def test_node_circuit_verifies_the_reference_golden_proof_in_circuit():
+    """The in-circuit verifier against reference data: a node circuit for the shape of wormhole/bench-data/common.bin, given the reference's
+    verifier data (verifier.bin: constants/sigmas cap + circuit digest) and the golden proof the Rust prover made (proof.bin), has a witness —
+    every transcript challenge, the vanishing identity, the FRI checks and all 280 Merkle openings hold as constraints — and forwards the
+    proof's 16 public inputs; any forged byte of the proof leaves it without one."""
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rd = lambda f: open(os.path.join(g, f), "rb").read()
+    common, vb, proof = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
+    vo = vb[:len(vb) - len(common)] if vb.endswith(common) and len(vb) > len(common) else vb
+    shape = ReferenceCircuitShape(common, vo)
+    node = BuiltCircuit.aggregation(shape.desc, 1); on = OracleCircuit(node.desc)
+    assert node.desc.zero_knowledge == 1 and node.desc.degree_bits == 14                  # the child's config (zk); 7,150 rows + 8,326 blinding rows
+    w, p = node.witness(node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [proof]), bytes(range(32)))
+    assert check_witness(on, w, p) is None
+    assert list(p) == list(np.frombuffer(proof[-128:], dtype="<u8"))
+    rng = np.random.default_rng(11)
+    for pos in [len(proof) - 1, 5, 3 * 512 + 40, len(proof) - 140] + [int(v) for v in rng.integers(0, len(proof), 8)]:
+        bad = bytearray(proof); bad[pos] ^= 1 << int(rng.integers(0, 8))
+        with pytest.raises(CircuitError):
+            node.witness(node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [bytes(bad)]), bytes(range(32)))

@@ -204,3 +204,23 @@ def test_every_built_circuit_proves_byte_equal_to_the_oracle(kind, zk):
     v = GpuVerifier(c.desc, gc.cap())
     assert v.verify(got) is None
     v.close(); gc.close()
+
+
+def test_the_reference_golden_proof_is_aggregated_on_the_device():
+    """A tree node over the reference's own proof: the node circuit built for wormhole/bench-data/common.bin verifies bench-data/proof.bin
+    (made by the Rust prover) in-circuit against verifier.bin, the device proves the node, and the node's proof — whose public inputs are the
+    golden proof's — verifies under the product verifier and the oracle verifier; bytes equal to the oracle prover's."""
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rd = lambda f: open(os.path.join(g, f), "rb").read()
+    common, vb, proof = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
+    vo = vb[:len(vb) - len(common)] if vb.endswith(common) and len(vb) > len(common) else vb
+    shape = ReferenceCircuitShape(common, vo)
+    node = BuiltCircuit.aggregation(shape.desc, 1)
+    w, p = node.witness(node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [proof]), bytes(range(32)))
+    gc, oc = GpuCircuit(node.desc), OracleCircuit(node.desc)
+    got = gc.prove(w, p, salt_seed=9)
+    assert got == oc.prove(w, p, salts=SynthCircuit("B").salts_keyed(TEST_SALT_KEY, 9))
+    assert list(np.frombuffer(got[-128:], dtype="<u8")) == list(np.frombuffer(proof[-128:], dtype="<u8"))
+    v = GpuVerifier(node.desc, gc.cap())
+    assert v.verify(got) is None and oc.verify(got) is None
+    v.close(); gc.close()
