@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """Where one aggregation-tree node's time goes (run on the GPU box): input encoding, witness generation (QPC_TIMING=1 prints its phases),
 host-to-device copy + proof. Leaves: synthetic preset B (zk, 2^14)."""
-import ctypes, importlib, os, sys, time
+import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-import numpy as np
 try:
     import torch
     torch.cuda.init()

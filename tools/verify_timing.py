@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phases of qpgpu_verify_batch on the reference's golden proof (run on the GPU box; QPGPU_VERIFY_TIMING=1 prints them per call)."""
-import importlib, os, sys, time
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch; torch.cuda.init()

@@ -1,7 +1,6 @@
 import sys, time, importlib, os
 sys.path.insert(0, os.getcwd())
 ffi = importlib.import_module("zk-circuits_amd.ffi"); th = importlib.import_module("zk-circuits_amd.test_helpers")
-import numpy as np
 def bench(c, x, key, label):
     o = c.witness(x, key, threads=1); ref = o[0].copy()
     for thr in (1, 2, 4, 8, 16):

@@ -5,8 +5,6 @@
 is `VerifierCircuitData::verify` — here through qpgpu_verify_batch (include/qpgpu.h): Merkle openings on the device, transcript and
 field arithmetic on the host. `verify_batch` is the many-proofs form the aggregator uses when it takes in leaf proofs. `new(config)`
 builds the verifier data of the synthetic circuit package that stands in for `WormholeCircuit::new(config).build_verifier()`."""
-import ctypes
-import numpy as np
 from . import ffi
 
 
