@@ -43,6 +43,7 @@ class WormholeProofAggregator:
         self.config = config or TreeAggregationConfig()
         self.proofs_buffer = []
         self.chunk_prover = chunk_prover
+        self._witness_pool = []         # reusable (wires, public_inputs) buffers of prove_leaves
 
     @staticmethod
     def from_circuit_config(circuit_config, device=0):
@@ -80,34 +81,50 @@ class WormholeProofAggregator:
         Salts: ChaCha8(salt_key, stream i) for leaf i with a fresh OS-RNG key per call, unless `salt_seed` is given (tests: the
         public test key with stream salt_seed + i, reproducible by the oracle)."""
         cd = self.leaf_circuit_data
+        n = len(circuit_inputs_list)
         cores = len(os.sched_getaffinity(0))
-        inner = max(1, min(8, cores // max(1, len(circuit_inputs_list))))  # threads inside one witness when only a few are generated at once
-
-        def witness(ci):
-            if not isinstance(ci, SyntheticInputs):                       # the reference's CircuitInputs on the built wormhole circuit
-                return cd.generate_witness(ci, os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY, threads=inner)
-            return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
-        if len(circuit_inputs_list) > 1 and not isinstance(circuit_inputs_list[0], SyntheticInputs):
-            from concurrent.futures import ThreadPoolExecutor            # witness generation releases the GIL (ctypes): one leaf per host core
-            with ThreadPoolExecutor(max_workers=min(len(circuit_inputs_list), max(1, len(os.sched_getaffinity(0)) - 1))) as ex:
-                ws, ps = zip(*ex.map(witness, circuit_inputs_list))
-        else:
-            ws, ps = zip(*[witness(ci) for ci in circuit_inputs_list])
-        b = len(ws)
-        wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w in ws])
-        pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for p in ps])
-        o = ffi.ProveOpts()
+        real = n > 0 and not isinstance(circuit_inputs_list[0], SyntheticInputs)
+        outer = 1 if n <= 1 else min(n, max(2, cores // 2))                 # witnesses generated at once
+        inner = max(1, min(8, cores // outer))                              # threads inside one witness (the circuit's independent segments)
+        blinding = os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY
         if salt_seed is not None:
-            key, o.salt_stream = ffi.TEST_SALT_KEY, salt_seed
+            key, base = ffi.TEST_SALT_KEY, salt_seed
         else:
-            key, o.salt_stream = (salt_key or os.urandom(32)), 0
-        keep = ffi.set_salt_key(o, key)      # noqa: F841
-        buf = ctypes.create_string_buffer(cd.proof_size * b)
-        lens = (ctypes.c_size_t * b)()
-        ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf,
-                                              cd.proof_size, lens))
-        for i in range(b):
-            self.push_proof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs))
+            key, base = (salt_key or os.urandom(32)), 0
+        # witness matrices of built circuits are reused from call to call (a fresh 17.7 MB matrix costs more in page faults than the generation)
+        pool = self._witness_pool
+        if real:
+            built = cd._built
+            while len(pool) < n:
+                pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
+
+        def witness(ci, slot):
+            if not isinstance(ci, SyntheticInputs):                         # the reference's CircuitInputs on the built wormhole circuit
+                return built.witness(ci.fill_targets(built.kind), blinding, out=pool[slot], threads=inner)
+            return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
+
+        def prove(wit, first):                                             # one device batch; leaf i takes salt stream base + i
+            b = len(wit)
+            wp = (ctypes.c_void_p * b)(*[w.ctypes.data for w, _ in wit])
+            pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
+            o = ffi.ProveOpts()
+            o.salt_stream = base + first
+            keep = ffi.set_salt_key(o, key)      # noqa: F841
+            buf = ctypes.create_string_buffer(cd.proof_size * b)
+            lens = (ctypes.c_size_t * b)()
+            ffi.check(ffi.lib().qpgpu_prove_batch(cd._circuit, b, wp, pp, cd.num_public_inputs, ctypes.byref(o), buf, cd.proof_size, lens))
+            for i in range(b):
+                self.push_proof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs))
+        if not real or n == 1:
+            prove([witness(ci, i) for i, ci in enumerate(circuit_inputs_list)], 0)
+            return
+        # host threads generate witnesses (the library releases the GIL) while the device proves the groups already complete
+        from concurrent.futures import ThreadPoolExecutor
+        GROUP = 16
+        with ThreadPoolExecutor(max_workers=outer) as ex:
+            futures = [ex.submit(witness, ci, i) for i, ci in enumerate(circuit_inputs_list)]
+            for first in range(0, n, GROUP):
+                prove([f.result() for f in futures[first:first + GROUP]], first)
 
     def aggregate(self, dummy_proof=None, chunk_prover=None):
         """aggregator.rs:74-92. With a `chunk_prover` (see aggregate_to_tree) the padded leaves are aggregated to the root proof;
