@@ -363,7 +363,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   if (d.num_wires < 1 || d.num_wires > 4096 || d.num_routed < 1 || d.num_routed > d.num_wires) return set_err(QPGPU_ERR_ARG, "need 1 <= num_routed <= num_wires <= 4096");
   if (d.fri_cap_height > d.degree_bits + d.fri_rate_bits || d.fri_cap_height > 20) return set_err(QPGPU_ERR_ARG, "cap height exceeds tree");
   if (d.fri_pow_bits > 40) return set_err(QPGPU_ERR_ARG, "proof_of_work_bits out of range");
-  if (d.num_public_inputs > 4096) return set_err(QPGPU_ERR_ARG, "too many public inputs");
+  if (d.num_public_inputs > (1u << 20)) return set_err(QPGPU_ERR_ARG, "too many public inputs");
   if (d.num_challenges < 1 || d.num_challenges > 2) return set_err(QPGPU_ERR_ARG, "num_challenges must be 1 or 2");
   if (d.num_gates > MAX_GATES || d.num_gates == 0) return set_err(QPGPU_ERR_ARG, "bad gate count");
   if (d.fri_num_layers > MAX_FRI_LAYERS) return set_err(QPGPU_ERR_ARG, "too many FRI layers");
