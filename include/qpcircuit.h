@@ -100,6 +100,10 @@ int qpv_fill_targets(const qpv_vote_inputs* in, uint64_t* inputs, size_t cap, si
  * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built from the leaf gate set; its layout is
  * unpinned like every circuit here. */
 int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner, uint32_t num_proofs, qpc_circuit** out);
+/* The same with the node's own zero-knowledge setting: 2 = as the children (what the function above and the reference do), 0 / 1 = off / on.
+ * A node's witness is made of public data only (its children's proofs and their verifier data), so a node without blinding rows gives nothing
+ * away about the leaves' witnesses — and has half the rows (2^14 instead of 2^15 for two zk children). */
+int qpc_aggregation_circuit_build_ex(const qpgpu_circuit_desc* inner, uint32_t num_proofs, uint32_t zero_knowledge, qpc_circuit** out);
 /* set_verifier_data_target + set_proof_with_pis_target: the node circuit's input-target values from the inner circuit's verifier data
  * (constants_sigmas_cap [2^cap_height][4], circuit_digest) and `count` proofs (ProofWithPublicInputs::to_bytes, `stride` bytes apart).
  * *len = count of values; inputs may be NULL to query it. A proof that does not verify fails in qpc_generate_witness. */

@@ -224,3 +224,15 @@ def test_the_reference_golden_proof_is_aggregated_on_the_device():
     v = GpuVerifier(node.desc, gc.cap())
     assert v.verify(got) is None and oc.verify(got) is None
     v.close(); gc.close()
+
+
+def test_nodes_without_zero_knowledge_over_zk_leaves():
+    """RecursiveChunkProver(node_zero_knowledge=False): zk leaves, nodes without blinding rows (2^14 rows instead of 2^15; a node's witness is
+    its children's proofs and verifier data, all public). The default stays the reference's (nodes take their children's config)."""
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+    leaves = [pkg.WormholeProver(cd).commit(th.circuit_test_inputs()).prove() for _ in range(4)]
+    prover = pkg.RecursiveChunkProver(cd, node_zero_knowledge=False)
+    root = pkg.aggregate_to_tree(leaves, pkg.TreeAggregationConfig(2, 2), prover)
+    assert root.circuit_data.desc.zero_knowledge == 0 and root.circuit_data.desc.degree_bits == 14
+    pkg.WormholeVerifier.new(None, circuit_data=root.circuit_data).verify(root.proof)
+    assert root.proof.public_inputs == [x for l in leaves for x in l.public_inputs]

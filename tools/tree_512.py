@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] on ONE GPU (rehearsal of the 8-GPU run): 512 wormhole leaf proofs from CircuitInputs (zk config), aggregated with real
-recursion (branching 2, depth 9) to one root proof, verified. Prints one JSON line. Run on the GPU box: python tools/tree_512.py [leaves]"""
+recursion (branching 2, depth 9) to one root proof, verified. Prints one JSON line. Run on the GPU box: python tools/tree_512.py [leaves [plain-nodes]]"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,13 +10,14 @@ import torch
 torch.cuda.init()
 pkg = importlib.import_module("zk-circuits_amd"); th = pkg.test_helpers
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+node_zk = None if len(sys.argv) < 3 or sys.argv[2] != "plain-nodes" else False      # "plain-nodes": nodes without zero knowledge (2^14 rows)
 depth = int(round(np.log2(n)))
 cfg = pkg.CircuitConfig.standard_recursion_zk_config()
 cd = pkg.WormholeCircuitData.get(cfg)
 inputs = []
 for i in range(n):
     ci = th.circuit_test_inputs(); ci.public.exit_account = pkg.BytesDigest(int(i + 1).to_bytes(8, "little") + bytes(24)); inputs.append(ci)
-prover = pkg.RecursiveChunkProver(cd)
+prover = pkg.RecursiveChunkProver(cd, node_zero_knowledge=node_zk)
 agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), prover)
 t0 = time.perf_counter()
 warm = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), prover)      # builds the node circuit of every level, warms workspaces
@@ -34,5 +35,5 @@ ok = all(int.from_bytes(bytes(l.exit_account[:8]), "little") == i + 1 for i, l i
 print(json.dumps({"workload": "BASELINE configs[3] on one GPU: %d wormhole leaf proofs (zk) from CircuitInputs -> recursive aggregation tree (branching 2, depth %d) -> root" % (n, depth),
                   "leaf_stage_s": round(t2 - t1, 3), "leaf_proofs_per_s": round(n / (t2 - t1), 1), "tree_stage_s": round(t3 - t2, 3), "nodes": n - 1,
                   "total_s": round(t3 - t1, 3), "proofs_per_s_end_to_end": round(n / (t3 - t1), 1), "root_verify_ms": round((t4 - t3) * 1e3, 2),
-                  "root_degree_bits": int(root.circuit_data.desc.degree_bits), "root_public_inputs": len(root.proof.public_inputs), "root_bytes": len(root.proof),
+                  "root_degree_bits": int(root.circuit_data.desc.degree_bits), "nodes_zero_knowledge": bool(root.circuit_data.desc.zero_knowledge), "root_public_inputs": len(root.proof.public_inputs), "root_bytes": len(root.proof),
                   "leaf_public_inputs_in_order": bool(ok), "node_circuits_build_and_warm_s": round(t_build, 1)}))

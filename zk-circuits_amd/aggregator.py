@@ -194,12 +194,15 @@ class RecursiveChunkProver:
     the node circuit for every chunk (tree.rs:112-128); every chunk of a level has the same circuit, so it is built once per level here.
     Level 0 takes proofs of `leaf_circuit_data`; level k takes proofs of level k-1's node circuit."""
 
-    def __init__(self, leaf_circuit_data, device=0, salt_seed=None):
-        """`salt_seed` (tests, benches): zero-knowledge node circuits take their blinding rows and salts from the public test key with
+    def __init__(self, leaf_circuit_data, device=0, salt_seed=None, node_zero_knowledge=None):
+        """`node_zero_knowledge`: None = nodes take their children's config as in the reference (zk leaves, zk nodes: 2^15 rows per node);
+        False = nodes without blinding rows and salts (2^14 rows: a node's witness is public data only — its children's proofs and verifier
+        data — so this gives nothing away about the leaves). `salt_seed` (tests, benches): zero-knowledge node circuits take their blinding rows and salts from the public test key with
         reproducible streams; without it both come from the OS RNG, fresh per level."""
         self.leaf = leaf_circuit_data
         self.device = device
         self.salt_seed = salt_seed
+        self.node_zero_knowledge = node_zero_knowledge
         self._levels = {}               # (level, children per node) -> (WormholeCircuitData of the node circuit, inner circuit data, its cap, its digest)
         self._level_width = {}          # level -> children per node of the (full) chunks proved at that level
         self._pool = {}                 # (level, children per node) -> reusable (wires, public_inputs) buffers
@@ -209,7 +212,7 @@ class RecursiveChunkProver:
         key = (level, width)
         if key not in self._levels:
             inner = self.leaf if level == 0 else self.level(level - 1, self._level_width.get(level - 1, width))[0]
-            node = ffi.BuiltCircuit.aggregation(inner.desc, width)
+            node = ffi.BuiltCircuit.aggregation(inner.desc, width, self.node_zero_knowledge)
             self._levels[key] = (WormholeCircuitData.from_built(node, self.device), inner, inner.constants_sigmas_cap(), list(inner.desc.circuit_digest))
         return self._levels[key]
 

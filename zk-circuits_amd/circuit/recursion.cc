@@ -385,13 +385,19 @@ static Builder* qpc_internal_builder(qpc_circuit* c) { return &c->b; }
 static void qpc_internal_set_aux(qpc_circuit* c, void* aux, void (*del)(void*)) { c->aux = aux; c->aux_del = del; }
 static void* qpc_internal_aux(const qpc_circuit* c) { return c->kind == QPC_AGGREGATION ? c->aux : nullptr; }
 
+extern "C" int qpc_aggregation_circuit_build_ex(const qpgpu_circuit_desc* inner_desc, uint32_t num_proofs, uint32_t zero_knowledge, qpc_circuit** out);
 extern "C" int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner_desc, uint32_t num_proofs, qpc_circuit** out) {
+  return qpc_aggregation_circuit_build_ex(inner_desc, num_proofs, 2, out);
+}
+extern "C" int qpc_aggregation_circuit_build_ex(const qpgpu_circuit_desc* inner_desc, uint32_t num_proofs, uint32_t zero_knowledge, qpc_circuit** out) {
   try {
     if (!inner_desc || !out || num_proofs < 1 || num_proofs > 16) { qpc_internal_set_error("bad argument"); return QPGPU_ERR_ARG; }
     AggInfo* info = new AggInfo(); info->count = num_proofs;
     const std::string e = info->inner.init(*inner_desc);
     if (!e.empty()) { delete info; qpc_internal_set_error(e.c_str()); return QPGPU_ERR_ARG; }
-    qpc_circuit* c = qpc_internal_new_circuit(QPC_AGGREGATION, inner_desc->zero_knowledge != 0);   // CircuitBuilder::new(common_data.config.clone()) (tree.rs:111): zk leaves give zk nodes
+    // CircuitBuilder::new(common_data.config.clone()) (tree.rs:111): zk children give a zk node, unless the caller decides otherwise (_ex)
+    if (zero_knowledge > 2) { delete info; qpc_internal_set_error("zero_knowledge must be 0, 1 or 2 (= as the children)"); return QPGPU_ERR_ARG; }
+    qpc_circuit* c = qpc_internal_new_circuit(QPC_AGGREGATION, zero_knowledge == 2 ? inner_desc->zero_knowledge != 0 : zero_knowledge != 0);
     qpc_internal_set_aux(c, info, [](void* p) { delete (AggInfo*)p; });
     Builder& b = *qpc_internal_builder(c);
     const VerifierDataT vd = add_verifier_data_targets(b, info->inner);         // tree.rs:113-114

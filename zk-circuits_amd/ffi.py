@@ -223,6 +223,7 @@ def circuit_lib():
         L.qpw_public_inputs_from_felts.argtypes = [u64p, ctypes.c_size_t, ctypes.POINTER(WormholePublicInputsC)]
         L.qpv_fill_targets.argtypes = [ctypes.POINTER(VoteInputsC), u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.qpc_aggregation_circuit_build.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpc_aggregation_circuit_build_ex.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         L.qpc_aggregation_fill_targets.argtypes = [ctypes.c_void_p, u64p, u64p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, u64p,
                                                    ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.qpc_test_random_circuit.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), u64p, u64p,
@@ -303,12 +304,13 @@ class BuiltCircuit:
         return self, inputs, expected[:n.value]
 
     @classmethod
-    def aggregation(cls, inner_desc, num_proofs):
+    def aggregation(cls, inner_desc, num_proofs, zero_knowledge=None):
         """The circuit of one aggregation-tree node (aggregate_chunk, tree.rs:106-143): verifies `num_proofs` proofs of the circuit
-        `inner_desc` in-circuit and forwards their public inputs."""
+        `inner_desc` in-circuit and forwards their public inputs. `zero_knowledge`: None = as the children (the reference), or False / True."""
         self = cls.__new__(cls)
         h = ctypes.c_void_p()
-        circuit_check(circuit_lib().qpc_aggregation_circuit_build(ctypes.byref(inner_desc), num_proofs, ctypes.byref(h)))
+        circuit_check(circuit_lib().qpc_aggregation_circuit_build_ex(ctypes.byref(inner_desc), num_proofs, 2 if zero_knowledge is None else int(bool(zero_knowledge)),
+                                                                     ctypes.byref(h)))
         self.handle, self.kind = h, QPC_AGGREGATION
         self.desc = circuit_lib().qpc_circuit_desc(h).contents
         self.n = 1 << self.desc.degree_bits
