@@ -92,8 +92,9 @@ def test_synth_presets_and_desc():
 def test_proof_size_from_the_descriptor_alone():
     """ffi.proof_size_of == the reference's proof sizes for the two leaf shapes (132,712 / 148,932 bytes)."""
     ffi = importlib.import_module("zk-circuits_amd.ffi")
-    assert ffi.proof_size_of(SynthCircuit("A").desc) == 132712 and ffi.proof_size_of(SynthCircuit("B").desc) == 148932
-    assert ffi.proof_size_of(BuiltCircuit(QPC_WORMHOLE, False).desc) == 132712
+    a, b, w = SynthCircuit("A"), SynthCircuit("B"), BuiltCircuit(QPC_WORMHOLE, False)      # owners kept alive: the descriptors point into them
+    assert ffi.proof_size_of(a.desc) == 132712 and ffi.proof_size_of(b.desc) == 148932
+    assert ffi.proof_size_of(w.desc) == 132712
 
 
 def test_witness_generation_is_seeded():

@@ -65,7 +65,8 @@ def test_wormhole_circuit_shape_and_public_inputs(circuits):
     got = pkg.PublicCircuitInputs.try_from_slice(pis)                         # proof_can_be_deserialized, prover_tests.rs:22-47
     assert got == pkg.PublicCircuitInputs(1_000_000_000_000, pkg.BytesDigest(bytes(KATS["expected_nullifier_bytes"])),
                                           pkg.BytesDigest(bytes(KATS["expected_root_hash_bytes"])), pkg.BytesDigest(bytes([4] * 32)))
-    assert BuiltCircuit(QPC_WORMHOLE).desc.circuit_digest[:] == c.desc.circuit_digest[:]        # building is deterministic
+    again = BuiltCircuit(QPC_WORMHOLE)
+    assert again.desc.circuit_digest[:] == c.desc.circuit_digest[:]                            # building is deterministic
     assert czk.desc.circuit_digest[:] != c.desc.circuit_digest[:]
 
 
