@@ -69,12 +69,19 @@ def test_a_child_that_does_not_verify_cannot_be_witnessed(vote_leaf, level1):
     rng = np.random.default_rng(7)
     L = len(leaf)
     positions = [0, 3 * 512 + 9, L - 1, L - 8 * len(p) - 3, L // 2] + [int(v) for v in rng.integers(0, L, 10)]     # caps, openings, public inputs, pow witness, queries
-    for pos in positions:
+    positions += [int(v) for v in rng.integers(0, L, 25)]
+    rejected = 0
+    for pos in positions:                                                        # the node has a witness exactly when the host verifier accepts the child
         bad = bytearray(leaf); bad[pos] ^= 1 << int(rng.integers(0, 8))
-        if oc.verify(bytes(bad)) is None:
-            continue                                                             # (a flip the verifier does not see, e.g. inside a Merkle length byte that is re-derived)
-        with pytest.raises(CircuitError):
+        accepted = oc.verify(bytes(bad)) is None
+        try:
             node.witness(node.aggregation_targets(oc.cap(), inner.desc.circuit_digest, [leaf, bytes(bad)]))
+            witnessed = True
+        except CircuitError:
+            witnessed = False
+        assert witnessed == accepted, (pos, accepted, witnessed)
+        rejected += not accepted
+    assert rejected >= len(positions) - 2
     wrong_cap = oc.cap().copy(); wrong_cap[3, 1] ^= np.uint64(1)                  # other verifier data: the constants/sigmas openings no longer reach the cap
     with pytest.raises(CircuitError):
         node.witness(node.aggregation_targets(wrong_cap, inner.desc.circuit_digest, [leaf, leaf]))

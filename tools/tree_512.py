@@ -17,6 +17,8 @@ cd = pkg.WormholeCircuitData.get(cfg)
 inputs = []
 for i in range(n):
     ci = th.circuit_test_inputs(); ci.public.exit_account = pkg.BytesDigest(int(i + 1).to_bytes(8, "little") + bytes(24)); inputs.append(ci)
+if os.environ.get("TREE_GROUP"):
+    pkg.RecursiveChunkProver.GROUP = int(os.environ["TREE_GROUP"])       # nodes per device batch (experiment)
 prover = pkg.RecursiveChunkProver(cd, node_zero_knowledge=node_zk)
 agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), prover)
 t0 = time.perf_counter()
@@ -24,6 +26,8 @@ warm = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), prov
 warm.prove_leaves(inputs[:2]); w = [p for p in warm.proofs_buffer]
 for lvl in range(depth):
     w = [prover([w[0], w[-1]], lvl).proof] * 2
+if os.environ.get("TREE_WARM"):
+    wa = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), prover); wa.prove_leaves(inputs); wa.aggregate()
 t_build = time.perf_counter() - t0
 print("node circuits built and warmed in %.1f s" % t_build, file=sys.stderr, flush=True)
 t1 = time.perf_counter(); agg.prove_leaves(inputs); t2 = time.perf_counter()
