@@ -236,3 +236,22 @@ def test_nodes_without_zero_knowledge_over_zk_leaves():
     assert root.circuit_data.desc.zero_knowledge == 0 and root.circuit_data.desc.degree_bits == 14
     pkg.WormholeVerifier.new(None, circuit_data=root.circuit_data).verify(root.proof)
     assert root.proof.public_inputs == [x for l in leaves for x in l.public_inputs]
+
+
+def test_prover_and_verifier_from_file_e2e(tmp_path):
+    """circuit_data_tests.rs:96-183: write the circuit's files, create prover and verifier from the files alone, commit hand-built CircuitInputs
+    (empty storage proof: the root hash is the leaf-inputs hash; funding account [2; 32], amount 1000), prove, verify. The prover artefact
+    is this backend's circuit package; its digest identifies the wormhole circuit, so the loaded prover generates witnesses like a built one."""
+    pkg.generate_circuit_binaries(str(tmp_path), include_prover=True)                    # circuit-builder: standard_recursion_config
+    prover = pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin"))
+    verifier = pkg.WormholeVerifier.new_from_files(str(tmp_path / "verifier.bin"), str(tmp_path / "common.bin"))
+    secret = bytes([1] * 32)
+    funding = pkg.BytesDigest(bytes([2] * 32)); unspendable = pkg.unspendable_account_from_secret(secret)
+    amount = 1000
+    leaf = [0, 0] + funding.to_felts() + unspendable.to_felts() + [(amount >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)]
+    root = pkg.BytesDigest.from_felts([int(v) for v in pkg.ffi.hash_no_pad(leaf)])
+    inputs = pkg.CircuitInputs(pkg.PublicCircuitInputs(amount, pkg.nullifier_from_preimage(secret, 0), root, pkg.BytesDigest(bytes([2] * 32))),
+                               pkg.PrivateCircuitInputs(secret, pkg.ProcessedStorageProof([], []), 0, funding, unspendable))
+    proof = prover.commit(inputs).prove()
+    verifier.verify(proof)
+    assert pkg.PublicCircuitInputs.try_from_proof(proof) == inputs.public

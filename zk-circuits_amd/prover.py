@@ -107,7 +107,7 @@ class WormholeCircuitData:
     @classmethod
     def from_package(cls, package_bytes, device=0):
         """Resident circuit from a circuit package (ffi.write_package / qpgpu_package_write) — the artefact path of
-        WormholeProver::new_from_bytes (wormhole/prover/src/lib.rs:105-137). No synthetic witness source: commit() needs an explicit witness."""
+        WormholeProver::new_from_bytes (wormhole/prover/src/lib.rs:105-137). A package of the wormhole circuit commits CircuitInputs like a built one; any other needs an explicit witness."""
         self = cls.__new__(cls)
         self.config = None
         self._package = ffi.CircuitPackage(package_bytes)       # owns the arrays desc points into
@@ -122,6 +122,14 @@ class WormholeCircuitData:
         self._circuit = ctypes.c_void_p()
         ffi.check(L.qpgpu_circuit_create(self._ctx, ctypes.byref(self.desc), ctypes.byref(self._circuit)))
         self.proof_size = L.qpgpu_proof_size(self._circuit)
+        # prover.bin carries the witness generators; the package carries the circuit's digest, which binds every constants/sigmas value: if it is
+        # the digest of the wormhole circuit this library builds for the package's config, that circuit's generators are the package's
+        try:
+            b = ffi.BuiltCircuit(ffi.QPC_WORMHOLE, bool(self.desc.zero_knowledge))
+            if list(b.desc.circuit_digest) == list(self.desc.circuit_digest) and b.desc.degree_bits == self.desc.degree_bits:
+                self._built = b
+        except (ImportError, ffi.CircuitError):
+            pass
         return self
 
     @classmethod
