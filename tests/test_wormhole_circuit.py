@@ -358,3 +358,23 @@ def test_public_inputs_equal_those_of_the_reference_dummy_proofs(circuits, name)
     _, p = c.witness(th.circuit_test_inputs().fill_targets())
     assert list(np.frombuffer(blob[-128:], dtype="<u8")) == [int(x) for x in p]
     assert int.from_bytes(blob[-136:-128], "little") == 16 and len(blob) == pkg.ffi.proof_size_of(c.desc)
+
+
+def test_amount_and_count_limb_encodings_round_trip():
+    """utils_tests.rs:11-156: u128 <-> four 32-bit limbs (most significant first) and u64 <-> two limbs, through the input encoding of the
+    storage-proof fragment (the last four / the first two of its leaf targets) and PublicCircuitInputs::try_from_slice."""
+    base = th.circuit_test_inputs()
+    for num in [0, 1, 0x1234567890abcdef, (1 << 128) - 1, (1 << 96) - 1, (1 << 64) | 0xabcdef]:
+        ci = copy.deepcopy(base); ci.public.funding_amount = num
+        x = [int(v) for v in ci.fill_targets(QPC_STORAGE_PROOF)]
+        assert x[-4:] == [(num >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)]
+        pis = [0] * 8 + x[-4:] + [0] * 4
+        assert pkg.PublicCircuitInputs.try_from_slice(pis).funding_amount == num
+    for count in [0, 1, 0x12345678, (1 << 64) - 1, (1 << 32) - 1, (1 << 32) | 0xabcdef]:
+        ci = copy.deepcopy(base); ci.private.transfer_count = count
+        x = [int(v) for v in ci.fill_targets(QPC_NULLIFIER)]
+        assert x[-2:] == [count >> 32, count & 0xFFFFFFFF]                       # Nullifier targets: hash (4), secret (8), transfer_count (2)
+    limbs = [[0, 0, 0, 0], [1, 1, 1, 1], [0x1234567, 0xabcdef, 0x1234567, 0xabcdef], [0xFFFFFFFF] * 4, [0, 0xFFFFFFFF, 0, 0xFFFFFFFF], [0xFFFFFFFF, 0, 0xFFFFFFFF, 0]]
+    for l in limbs:                                                                # felts -> u128 -> felts
+        num = pkg.PublicCircuitInputs.try_from_slice([0] * 8 + l + [0] * 4).funding_amount
+        assert [(num >> (96 - 32 * i)) & 0xFFFFFFFF for i in range(4)] == l
