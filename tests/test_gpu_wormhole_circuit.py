@@ -255,3 +255,25 @@ def test_prover_and_verifier_from_file_e2e(tmp_path):
     proof = prover.commit(inputs).prove()
     verifier.verify(proof)
     assert pkg.PublicCircuitInputs.try_from_proof(proof) == inputs.public
+
+
+@pytest.mark.parametrize("zk", [False, True])
+def test_aggregate_proofs_into_tree_like_the_reference_tests(zk):
+    """aggregator_tests.rs:11-112 as written there: from_circuit_config, push one leaf proof (push_proof_to_buffer), fill the buffer
+    (push_proof_to_full_buffer: the ninth push fails), aggregate the default tree of 2^3 leaves (aggregate_proofs_into_tree), every leaf's
+    public inputs come back out of the aggregated proof, and the aggregated proof verifies with its own circuit data."""
+    config = pkg.CircuitConfig.standard_recursion_zk_config() if zk else pkg.CircuitConfig.standard_recursion_config()
+    proof = pkg.WormholeProver.new(config).commit(th.circuit_test_inputs()).prove()
+    public_inputs = pkg.PublicCircuitInputs.try_from_proof(proof)
+    aggregator = pkg.WormholeProofAggregator.from_circuit_config(config)
+    aggregator.push_proof(proof)
+    assert len(aggregator.proofs_buffer) == 1
+    for _ in range(aggregator.config.num_leaf_proofs - 1):
+        aggregator.push_proof(proof)
+    with pytest.raises(RuntimeError, match="proof buffer is full"):
+        aggregator.push_proof(proof)
+    assert len(aggregator.proofs_buffer) == aggregator.config.num_leaf_proofs == 8
+    aggregated = aggregator.aggregate()
+    leaves = aggregator.extract_leaf_public_inputs(aggregated.proof)
+    assert len(leaves) == 8 and all(l == public_inputs for l in leaves)
+    pkg.WormholeVerifier.new(None, circuit_data=aggregated.circuit_data).verify(aggregated.proof)
