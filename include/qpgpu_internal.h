@@ -34,6 +34,7 @@ int qpgpu_last_stage_ms(double* out, int cap);
 
 /* ---- 3. kernel test hooks */
 int qpgpu_test_permute(uint64_t* states /*[count][12]*/, size_t count);
+int qpgpu_test_permute_form(uint64_t* states /*[count][12]*/, size_t count, int form /* 0 literal, 1 fast partial rounds, -1 default */);
 /* mode 0 forward DIF, 1 forward DIT, 2 inverse DIF, 3 inverse DIT (unscaled); data [count][2^log_n] in place */
 int qpgpu_test_ntt(uint64_t* data, int count, int log_n, int mode);
 int qpgpu_test_lde(const uint64_t* coeffs, int count, int log_n, int log_cosets, uint64_t shift, uint64_t* out);
@@ -49,6 +50,7 @@ double qpgpu_test_host_permute_ns(int iters);
 double qpgpu_test_sync_roundtrip_us(int iters);
 double qpgpu_test_sync_roundtrip_us2(int iters, int mode);
 double qpgpu_bench_permute(size_t count, int iters);
+double qpgpu_bench_permute_form(size_t count, int iters, int form /* as qpgpu_test_permute_form */);
 double qpgpu_bench_lde(int count, int log_n, int iters, int force_generic);
 
 #ifdef __cplusplus

@@ -47,7 +47,7 @@ def dev_leaf_hash(rows, mode):
     """rows: [num][width] -> [num][4] digests through the device leaf kernel of the given form (hash_or_noop per row)."""
     rows = np.asarray(rows, dtype=np.uint64)
     num, width = rows.shape
-    reps = 256 // np.gcd(num, 256) if mode == 2 else 1     # the fused form takes whole blocks of 256 leaves: replicate the rows
+    reps = 256 // np.gcd(num, 256) if mode in (2, 4) else 1     # the fused form takes whole blocks of 256 leaves: replicate the rows
     tiled = np.tile(rows, (reps, 1))
     cols = np.ascontiguousarray(tiled.T)             # column-major [width][num]
     out = np.zeros((tiled.shape[0], 4), dtype=np.uint64)
@@ -71,7 +71,7 @@ def dev_two_to_one(left, right, mode):
     return out
 
 
-LEAF_MODES = [0, 1, 2]
+LEAF_MODES = [0, 1, 2, 3, 4]      # per-lane, 2-lane pair, fused levels; 3 / 4 = per-lane / fused with the fast form of the partial rounds
 
 
 @pytest.mark.parametrize("mode", LEAF_MODES)
@@ -116,7 +116,7 @@ def golden():
     return shape, parse_proof(shape.desc, pb), replay_transcript(shape.desc, pb)
 
 
-@pytest.mark.parametrize("leaf_mode,node_mode", [(0, 0), (1, 1), (2, 2), (0, 3)])
+@pytest.mark.parametrize("leaf_mode,node_mode", [(0, 0), (1, 1), (2, 2), (0, 3), (3, 0), (4, 1)])
 def test_golden_proof_initial_tree_paths_on_device(golden, leaf_mode, node_mode):
     """4 oracles x 28 queries: device leaf hash of the golden rows, 13 device 2-to-1 levels, then the golden caps."""
     shape, p, tr = golden

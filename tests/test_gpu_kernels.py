@@ -8,17 +8,27 @@ pytestmark = pytest.mark.gpu
 GEN = 14293326489335486720
 
 
-def test_poseidon_permute_batch():
+@pytest.mark.parametrize("form", [0, 1])
+def test_poseidon_permute_batch(form):
+    """form 0: literal partial rounds; 1: the fast form (one S-box, one 11-term dot product, 11 multiply-adds per round) the leaf-hash kernels
+    use where the chip is full. Inputs include the extremes of the lazy arithmetic (0, p-1, 2^32-1 patterns)."""
     rng = np.random.default_rng(1)
     st = rand_felts(rng, (1000, 12))
     st[1] = 0
     st[2] = np.arange(12, dtype=np.uint64)
+    P = 0xFFFFFFFF00000001
+    st[3] = P - 1
+    st[4] = 0xFFFFFFFF
+    st[5] = 0xFFFFFFFF00000000
+    st[6, ::2] = P - 1; st[6, 1::2] = 0
+    st[7, 0] = P - 1; st[7, 1:] = 0
+    st[8, 0] = 0; st[8, 1:] = P - 1
     exp = st.copy()
     O = oracle()
     for i in range(exp.shape[0]):
         O.orc_permute(ptr(exp[i]))
     got = st.copy()
-    gpu_check(qpgpu().qpgpu_test_permute(ptr(got), got.shape[0]))
+    gpu_check(qpgpu().qpgpu_test_permute_form(ptr(got), got.shape[0], form))
     assert np.array_equal(got, exp)
     assert got[1, 0] == 0x3c18a9786cb0b359 and got[2, 0] == 0xd64e1e3efc5b8e9e   # SURVEY.md App. A.2 vectors
 

@@ -118,3 +118,23 @@ if __name__ == "__main__":
           f.write("#define QP_POSEIDON_FAST_WHAT \\\n" + ", \\\n".join("  {" + arr(S[t][1]) + "}" for t in range(22)) + "\n")
           f.write("#define QP_POSEIDON_FAST_V \\\n" + ", \\\n".join("  {" + arr(S[t][2]) + "}" for t in range(22)) + "\n")
       print("wrote", path)
+    # Device tables (csrc only): the dot products of the fast form take each constant a as 27/27/10-bit limbs of a and of a' = a*2^32 mod p,
+    # so that a*x = a*x_lo + a'*x_hi is six 32x32 multiply-adds whose column sums over 22 terms stay below 2^64 (poseidon_dev.h, dot11_dev).
+    def limbs(a):
+        out = []
+        for v in (a, a * (1 << 32) % P):
+            l = [v & 0x7FFFFFF, (v >> 27) & 0x7FFFFFF, v >> 54]
+            assert l[0] >= 1 and l[2] < 1024                      # dot11_dev's X0 - X2 >= 0 argument needs a nonzero low limb
+            out += l
+        return out
+    def arr32(xs): return ", ".join("0x%08xu" % x for x in xs)
+    path = os.path.join(os.path.dirname(__file__), "..", "zk-circuits_amd", "csrc", "poseidon_fast_dev_constants.h")
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_poseidon_fast.py; do not edit. Per constant a: limbs (27, 27, 10 bits) of a, then of a*2^32 mod p.\n#pragma once\n")
+        f.write("// round constants of rounds 0-3 followed by FIRST (what the fourth full round's MDS folds in instead of round 4's constants)\n")
+        f.write("#define QP_POSEIDON_FASTDEV_RC_HEAD " + ", ".join("0x%016xULL" % x for x in list(rc[:48]) + list(first)) + "\n")
+        f.write("#define QP_POSEIDON_FASTDEV_INIT \\\n" + ", \\\n".join("  " + arr32(limbs(x)) for row in init for x in row) + "\n")
+        f.write("// per round t: V[t][0..10] followed by Q[t+1] (0 after the last round): what one round's multiply-adds and the next S-box need\n")
+        f.write("#define QP_POSEIDON_FASTDEV_VQ \\\n" + ", \\\n".join("  " + ", ".join("0x%016xULL" % x for x in list(S[t][2]) + [Q[t + 1] if t < 21 else 0]) for t in range(22)) + "\n")
+        f.write("#define QP_POSEIDON_FASTDEV_WHAT \\\n" + ", \\\n".join("  " + arr32(limbs(x)) for t in range(22) for x in S[t][1]) + "\n")
+    print("wrote", path)

@@ -2,7 +2,8 @@
 """First-principles VALU issue bound of the one-permutation-per-lane Poseidon kernel (the body of k_leaves_colmajor / k_permute_batch).
 
   instructions: static gfx950 ISA of k_permute_batch (hipcc -S of csrc/merkle.hip), per loop, weighted by the trip counts of
-                poseidon_permute_dev (4 full rounds, 22 partial rounds, 3 full rounds, 1 unrolled final round);
+                poseidon_permute_dev (4 full rounds, the dense product in front of the partial rounds, 21 + 1 partial rounds in the
+                fast form, 3 full rounds, 1 unrolled final round);
   costs:        ns per wave-instruction per SIMD at saturation, measured on MI355X by tools/ubench/valu_rates2.hip
                 (profiles/r02_valu_issue_rates2.txt, column wps=8 "(ns)");
   bound:        (a) in cycles: a wave64 instruction occupies its SIMD for 2 cycles if the table shows it at the full rate (v_mov_b32, v_add_u32,
@@ -53,14 +54,23 @@ def main():
         subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
                                os.path.join(ROOT, "zk-circuits_amd", "csrc", "merkle.hip"), "-o", asm], stderr=subprocess.DEVNULL)
         lines = open(asm).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN2qp15k_permute_batchEPmm:"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN2qp15k_permute_batchILb1EEEvPmm:"))     # the fast form of the partial rounds
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
-    loops = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:.*Loop Header", l)]
-    backs = [i for i, l in enumerate(body) if "s_cbranch_scc1" in l]
-    assert len(loops) == 3 and len(backs) == 3, "expected the three round loops of poseidon_permute_dev"
-    segs = [("prologue", 0, loops[0], 1), ("full rounds 0-3", loops[0], backs[0] + 1, 4), ("partial rounds", loops[1], backs[1] + 1, 22),
-            ("full rounds 26-28", loops[2], backs[2] + 1, 3), ("final round + store", backs[2] + 1, len(body), 1)]
+    # the three round loops of poseidon_permute_dev, in program order: full rounds 0-3 (4 trips), the fast partial rounds (21 trips; the
+    # 22nd is peeled behind the loop) and full rounds 26-28 (3 trips); everything between and around them runs once
+    heads = [(i, re.match(r"^(\.LBB\d+_\d+):", l).group(1)) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:.*Loop Header", l)]
+    assert len(heads) == 3, "expected the three round loops of poseidon_permute_dev"
+    spans = []
+    for i, lab in heads:
+        back = next(j for j in range(i, len(body)) if re.search(r"s_cbranch_scc[01]\s+" + re.escape(lab) + r"\b", body[j]))
+        spans.append((i, back + 1))
+    names = [("full rounds 0-3", 4), ("partial rounds (fast form)", 21), ("full rounds 26-28", 3)]
+    between = ["prologue (load, first constants)", "dense 11x11 product + first S-box", "last partial round + constants of round 26", "final round + store"]
+    segs, pos = [], 0
+    for k, (a, b) in enumerate(spans):
+        segs.append((between[k], pos, a, 1)); segs.append((names[k][0], a, b, names[k][1])); pos = b
+    segs.append((between[3], pos, len(body), 1))
     total_ns, total_valu, total_nop, detail, unmeasured = 0.0, 0, 0, [], set()
     n_full = n_half = 0
     for name, a, b, trips in segs:

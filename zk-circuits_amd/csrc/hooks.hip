@@ -22,10 +22,13 @@ struct DevBuf {
 
 extern "C" {
 
-int qpgpu_test_permute(uint64_t* states, size_t count) {
+int qpgpu_test_permute(uint64_t* states, size_t count) { return qpgpu_test_permute_form(states, count, -1); }
+// form: 0 literal partial rounds, 1 fast partial rounds, -1 the library's default
+int qpgpu_test_permute_form(uint64_t* states, size_t count, int form) {
+  if (!states || form < -1 || form > 1) return set_err(-1, "bad argument");
   DevBuf d; HOOK_CHECK(d.alloc(count * 96));
   HOOK_CHECK(hipMemcpy(d.p, states, count * 96, hipMemcpyHostToDevice));
-  poseidon_permute_batch(d.u(), count, 0);
+  poseidon_permute_batch(d.u(), count, 0, form);
   HOOK_CHECK(hipGetLastError());
   HOOK_CHECK(hipMemcpy(states, d.p, count * 96, hipMemcpyDeviceToHost));
   return 0;
@@ -74,9 +77,10 @@ int qpgpu_test_merkle(const uint64_t* cols, int width, size_t num_leaves, int ca
 // ---- golden-vector replay hooks: the device sponge / 2-to-1 / FRI-leaf kernels on caller-supplied rows, one kernel form at a
 // time, so tests can pin each form directly to vectors the reference holds (KATs, the Merkle paths of bench-data/proof.bin).
 // Leaf digests only (hash_or_noop per row). cols: [width][num_leaves] column-major. mode 0: per-lane kernel (plain), 1: 2-lane pair
-// kernel, 2: per-lane kernel with fused levels 1-2 (needs num_leaves % 256 == 0; only the leaf digests are returned).
+// kernel, 2: per-lane kernel with fused levels 1-2 (needs num_leaves % 256 == 0; only the leaf digests are returned); 3 and 4: forms 0 and 2
+// with the fast form of the partial rounds (poseidon_dev.h).
 int qpgpu_test_leaf_hash(const uint64_t* cols, int width, size_t num_leaves, int mode, uint64_t* digests) {
-  if (!cols || !digests || width < 1 || num_leaves < 1 || mode < 0 || mode > 2 || (mode == 2 && num_leaves % 256)) return set_err(-1, "bad argument");
+  if (!cols || !digests || width < 1 || num_leaves < 1 || mode < 0 || mode > 4 || ((mode == 2 || mode == 4) && num_leaves % 256)) return set_err(-1, "bad argument");
   DevBuf c, d; HOOK_CHECK(c.alloc((size_t)width * num_leaves * 8)); HOOK_CHECK(d.alloc(num_leaves * 32 * 2));
   HOOK_CHECK(hipMemcpy(c.p, cols, (size_t)width * num_leaves * 8, hipMemcpyHostToDevice));
   merkle_leaves_colmajor_mode(c.u(), num_leaves, width, num_leaves, d.u(), mode, 0);
@@ -188,12 +192,13 @@ int qpgpu_test_calib_colsum(int width, size_t n, int iters) {
 }
 
 // Timing hook: G permutations/s of the one-permutation-per-lane kernel at a given grid size (occupancy sweep)
-double qpgpu_bench_permute(size_t count, int iters) {
+double qpgpu_bench_permute(size_t count, int iters) { return qpgpu_bench_permute_form(count, iters, -1); }
+double qpgpu_bench_permute_form(size_t count, int iters, int form) {
   DevBuf d; if (d.alloc(count * 96) != hipSuccess) return -1;
   (void)hipMemset(d.p, 0, count * 96);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  poseidon_permute_batch(d.u(), count, 0); (void)hipDeviceSynchronize();
-  (void)hipEventRecord(e0, 0); for (int i = 0; i < iters; i++) poseidon_permute_batch(d.u(), count, 0); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+  poseidon_permute_batch(d.u(), count, 0, form); (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0); for (int i = 0; i < iters; i++) poseidon_permute_batch(d.u(), count, 0, form); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)count * iters / (ms * 1e-3) / 1e9;

@@ -57,11 +57,11 @@ void salt_fill(u64* cols, size_t N, const SaltKey& key, u64 nonce, int oracle, h
 void check_canonical(const u64* data, size_t count, u64* flag, hipStream_t s);
 
 // ---------------- Poseidon / Merkle (merkle.hip) ----------------
-void poseidon_permute_batch(u64* states /*[count][12]*/, size_t count, hipStream_t s);
+void poseidon_permute_batch(u64* states /*[count][12]*/, size_t count, hipStream_t s, int form = -1);   // form: 0 literal / 1 fast partial rounds, -1 default
 // Leaf digests of `num_leaves` rows whose element j sits at cols + j*col_stride + leaf (column-major oracle), width felts per
 // leaf (hash_or_noop). digests: [num_leaves][4].
 // Returns how many levels above the leaves the launch already produced (the leaf kernel fuses levels 1-2 for big trees).
-int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s);
+int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s, bool chip_is_shared = false);
 // FRI layer leaves: leaf L = 2^arity_bits extension values (a[k], b[k]) k in [L*arity, (L+1)*arity), flattened a0,b0,a1,b1...
 void merkle_leaves_fri(const u64* a, const u64* b, int arity_bits, size_t num_leaves, u64* digests, hipStream_t s);
 // Builds all upper levels. levels: concatenated digests, level 0 (num_leaves) first, each level half the previous, down to

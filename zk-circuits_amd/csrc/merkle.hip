@@ -52,19 +52,23 @@ void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_ma
   hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq, extra, clear_extra ? 1 : 0);
 }
 
+template <bool FAST>
 __global__ void k_permute_batch(u64* states, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= count) return;
   u64 st[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) st[k] = states[i * 12 + k];
-  poseidon_permute_dev(st);
+  poseidon_permute_dev_t<FAST>(st);
 #pragma unroll
   for (int k = 0; k < 12; k++) states[i * 12 + k] = st[k];
 }
-void poseidon_permute_batch(u64* states, size_t count, hipStream_t s) {
+// form: 0 literal partial rounds, 1 fast partial rounds, -1 the library's choice for a full chip (QPGPU_POSEIDON_FAST=0 forces the literal form)
+void poseidon_permute_batch(u64* states, size_t count, hipStream_t s, int form) {
   if (!count) return;
-  hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
+  if (form < 0) form = opts().poseidon_fast != 0;
+  if (form) hipLaunchKernelGGL(k_permute_batch<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
+  else hipLaunchKernelGGL(k_permute_batch<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
 }
 
 // FUSE: the block (256 consecutive leaves) also produces its 128 level-1 and 64 level-2 nodes, saving two launches whose
@@ -72,8 +76,17 @@ void poseidon_permute_batch(u64* states, size_t count, hipStream_t s) {
 // (measured on MI355X: at N = 2^17 all 512 blocks run in lockstep, so the fused tail costs two more permutation
 // latencies at half/quarter occupancy and the leaf+levels total gets 5 % WORSE; profiles/r01 notes). Enabled from 2^20 leaves.
 static constexpr size_t PAIR_MAX_LEAVES = size_t(1) << 18;   // <= 4 waves/SIMD per-lane: the pair form fills the chip better
-template <bool FUSE>
-__global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
+// Occupancy targets (tools/ab_leaf_waves.sh on MI355X, V = 2^23 leaves, launch average): 3 waves/SIMD 30.6 ms, 4: 29.0, 5: 28.9, 6: 27.2 (80 VGPRs,
+// the saturated rate of the permutation, 2.6 G/s). The software-pipelined variant for small trees keeps 4 (126 VGPRs): a single proof
+// offers 2 waves/SIMD anyway and the tighter budgets spill inside its absorb loop.
+#ifndef QPGPU_LEAF_WAVES_FUSED
+#define QPGPU_LEAF_WAVES_FUSED 6
+#endif
+#ifndef QPGPU_LEAF_WAVES
+#define QPGPU_LEAF_WAVES 4
+#endif
+template <bool FUSE, bool FAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? QPGPU_LEAF_WAVES_FUSED : QPGPU_LEAF_WAVES, 8))) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
                                                          u64* level1, u64* level2) {
   __shared__ u64 sm[FUSE ? 256 * 4 : 4];
   size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -99,7 +112,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
         const int off2 = off + 8;
 #pragma unroll
         for (int k = 0; k < 8; k++) if (off2 + k < width) nxt[k] = cols[(size_t)(off2 + k) * col_stride + L];
-        poseidon_permute_dev(st);
+        poseidon_permute_dev_t<FAST>(st);
       }
     } else {
       for (int off = 0; off < width; off += 8) {
@@ -111,7 +124,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
 #pragma unroll
           for (int k = 0; k < 8; k++) if (k < m) st[k] = cols[(size_t)(off + k) * col_stride + L];
         }
-        poseidon_permute_dev(st);
+        poseidon_permute_dev_t<FAST>(st);
       }
     }
   }
@@ -127,7 +140,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
       for (int k = 0; k < 8; k++) st[k] = sm[t * 8 + k];
 #pragma unroll
       for (int k = 8; k < 12; k++) st[k] = 0;
-      poseidon_permute_dev(st);
+      poseidon_permute_dev_t<FAST>(st);
       size_t node = (size_t)blockIdx.x * 128 + t;
 #pragma unroll
       for (int k = 0; k < 4; k++) level1[node * 4 + k] = st[k];
@@ -143,7 +156,7 @@ __global__ void __launch_bounds__(256) k_leaves_colmajor(const u64* cols, size_t
       for (int k = 0; k < 8; k++) st[k] = sm[t * 8 + k];
 #pragma unroll
       for (int k = 8; k < 12; k++) st[k] = 0;
-      poseidon_permute_dev(st);
+      poseidon_permute_dev_t<FAST>(st);
       size_t node = (size_t)blockIdx.x * 64 + t;
 #pragma unroll
       for (int k = 0; k < 4; k++) level2[node * 4 + k] = st[k];
@@ -193,12 +206,19 @@ __global__ void __launch_bounds__(256) k_level_pair(const u64* in, u64* out, siz
 }
 
 // Returns the number of tree levels already produced above the leaves (0 or 2).
-int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s) {
+int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, int cap_height, u64* digests, hipStream_t s, bool chip_is_shared) {
   const bool fuse = (num_leaves % 256 == 0) && (num_leaves >> 2) >= (size_t(1) << cap_height) && num_leaves >= (size_t(1) << 20);
   dim3 grid((unsigned)((num_leaves + 255) / 256));
+  // Form of the partial rounds (poseidon_dev.h): fast from 2 waves per SIMD up (2^17 leaves) and for every tree of a batch, whose other proofs
+  // fill the chip; literal for a single proof's smaller trees. Same-box A/B (tools/ab_poseidon_form.sh, literal / fast, proofs/s): single proof of
+  // 2^17-leaf trees 266.5 / 270.3, of 2^16-leaf trees 378.8 / 364.5; batches of 64: 375 / 399; 2^23 leaves (V): 7.27 / 7.80.
+  const int pf = opts().poseidon_fast;
+  const bool fast = pf > 0 || (pf < 0 && (chip_is_shared || num_leaves >= (size_t(1) << 17)));
   if (fuse) {
-    hipLaunchKernelGGL(k_leaves_colmajor<true>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4,
-                       digests + (num_leaves + num_leaves / 2) * 4);
+    if (fast) hipLaunchKernelGGL((k_leaves_colmajor<true, true>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4,
+                                 digests + (num_leaves + num_leaves / 2) * 4);
+    else hipLaunchKernelGGL((k_leaves_colmajor<true, false>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4,
+                            digests + (num_leaves + num_leaves / 2) * 4);
     return 2;
   }
   // Measured (MI355X, 2^17 leaves): the pair form hashes leaves 9 % SLOWER than one permutation per lane (its per-lane stream is
@@ -209,7 +229,8 @@ int merkle_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t
     hipLaunchKernelGGL(k_leaves_colmajor_pair, dim3((unsigned)((2 * num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
     return 0;
   }
-  hipLaunchKernelGGL(k_leaves_colmajor<false>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+  if (fast) hipLaunchKernelGGL((k_leaves_colmajor<false, true>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+  else hipLaunchKernelGGL((k_leaves_colmajor<false, false>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
   return 0;
 }
 
@@ -422,8 +443,10 @@ void verify_paths(const u64* rows, int width, const u64* sibs, int depth, const 
 void merkle_leaves_colmajor_mode(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests, int mode, hipStream_t s) {
   dim3 grid((unsigned)((num_leaves + 255) / 256));
   if (mode == 1) hipLaunchKernelGGL(k_leaves_colmajor_pair, dim3((unsigned)((2 * num_leaves + 255) / 256)), dim3(256), 0, s, cols, col_stride, width, num_leaves, digests);
-  else if (mode == 2) hipLaunchKernelGGL(k_leaves_colmajor<true>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4, digests + (num_leaves + num_leaves / 2) * 4);
-  else hipLaunchKernelGGL(k_leaves_colmajor<false>, grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+  else if (mode == 2) hipLaunchKernelGGL((k_leaves_colmajor<true, false>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4, digests + (num_leaves + num_leaves / 2) * 4);
+  else if (mode == 3) hipLaunchKernelGGL((k_leaves_colmajor<false, true>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
+  else if (mode == 4) hipLaunchKernelGGL((k_leaves_colmajor<true, true>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, digests + num_leaves * 4, digests + (num_leaves + num_leaves / 2) * 4);
+  else hipLaunchKernelGGL((k_leaves_colmajor<false, false>), grid, dim3(256), 0, s, cols, col_stride, width, num_leaves, digests, (u64*)nullptr, (u64*)nullptr);
 }
 void merkle_level_mode(const u64* in, u64* out, size_t parents, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_level_lane, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, s, in, out, parents);

@@ -24,6 +24,8 @@ struct Options {
   int ntt_strided = 1;        // QPGPU_NTT_STRIDED=0: tiled multi-pass NTT only
   int ntt_m8 = 1;             // QPGPU_NTT_M8=0: radix-16 register passes instead of radix-256 LDS passes
   int verify_coop_max = 16384; // QPGPU_VERIFY_COOP_MAX: most Merkle openings per launch checked in the 16-lane form (0: always one lane per opening)
+  int poseidon_fast = -1;     // QPGPU_POSEIDON_FAST: form of the permutation's partial rounds in the leaf-hash kernels: -1 auto (fast where the chip is
+                              //   full: trees of >= 2^17 leaves and batches), 0 literal everywhere, 1 fast everywhere (same digests either way)
   int pow_first_shift = 0;    // QPGPU_POW_FIRST_SHIFT: the first proof-of-work launch tests 2^(pow_bits + shift) candidates (same proof bytes: the smallest witness wins)
 };
 const Options& opts();

@@ -49,7 +49,7 @@ void options_refresh_from_env() {
   o.pair_leaves = geti("QPGPU_PAIR_LEAVES", o.pair_leaves); o.pair_max = geti("QPGPU_PAIR_MAX", o.pair_max); o.coop_max = geti("QPGPU_COOP_MAX", o.coop_max);
   o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
-  o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift);
+  o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift); o.poseidon_fast = geti("QPGPU_POSEIDON_FAST", o.poseidon_fast);
   o.verify_coop_max = geti("QPGPU_VERIFY_COOP_MAX", o.verify_coop_max);
   const int nxt = 1 - g_opts_cur.load(std::memory_order_relaxed);
   g_opts[nxt] = o; g_opts_cur.store(nxt, std::memory_order_release);
@@ -291,7 +291,7 @@ static void commit_coeffs(qpgpu_circuit* c, Workspace* w, const u64* coeffs, int
   if (!fork_late) fork();
   int done = 0;
   { ProfScope ps(w, s, PF_LEAVES, (8.0 * width + 32.0) * N);
-    done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s); }
+    done = merkle_leaves_colmajor(lde, N, width, N, c->cap_h, dig, s, w->batch_mode); }
   if (fork_late) fork();
   { ProfScope ps(w, s, PF_LEVELS, 32.0 * 3 * N);
     merkle_levels(dig, N, c->cap_h, s, done, w->batch_mode); }

@@ -125,6 +125,7 @@ def lib():
         L.qpgpu_profile_name.restype = ctypes.c_char_p
         L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         L.qpgpu_test_permute.argtypes = [u64p, ctypes.c_size_t]
+        L.qpgpu_test_permute_form.argtypes = [u64p, ctypes.c_size_t, ctypes.c_int]
         L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.qpgpu_test_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u64p]
         L.qpgpu_test_merkle.argtypes = [u64p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, u64p]
@@ -141,6 +142,8 @@ def lib():
         L.qpgpu_test_sync_roundtrip_us2.argtypes = [ctypes.c_int, ctypes.c_int]
         L.qpgpu_bench_permute.restype = L.qpgpu_bench_lde.restype = ctypes.c_double
         L.qpgpu_bench_permute.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        L.qpgpu_bench_permute_form.restype = ctypes.c_double
+        L.qpgpu_bench_permute_form.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
         L.qpgpu_bench_lde.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib = L
     return _lib
