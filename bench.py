@@ -478,7 +478,8 @@ def main():
                 "saturated_G_perm_per_s": sat, "frac": round(pps / 1e9 / sat, 3) if sat else None,
                 "valu_instr_per_permutation": ib.get("valu_instr_per_permutation"), "source": "profiles/r02_poseidon_issue_bound.json",
                 "note": "integer-VALU issue bound = 1024 SIMDs x 64 lanes x 2.4 GHz / (2 N_full + 4 N_half) cycles per wave-permutation; "
-                        "a single 2^17-leaf proof only offers 2 waves/SIMD, the saturated figure needs >= 8"}
+                        "a single 2^17-leaf proof only offers 2 waves/SIMD, the saturated figure needs >= 8. Instruction count and ceilings are those of the "
+                        "fast form of the partial rounds, which the leaf hash uses from 2^17 leaves up and in batches (csrc/poseidon_dev.h)"}
 
     # whole-proof algorithmic bytes B(n, s) against the HBM peak
     d = sc.desc; n_, N_ = sc.n, sc.N

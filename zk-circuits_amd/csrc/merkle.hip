@@ -78,7 +78,8 @@ void poseidon_permute_batch(u64* states, size_t count, hipStream_t s, int form) 
 static constexpr size_t PAIR_MAX_LEAVES = size_t(1) << 18;   // <= 4 waves/SIMD per-lane: the pair form fills the chip better
 // Occupancy targets (tools/ab_leaf_waves.sh on MI355X, V = 2^23 leaves, launch average): 3 waves/SIMD 30.6 ms, 4: 29.0, 5: 28.9, 6: 27.2 (80 VGPRs,
 // the saturated rate of the permutation, 2.6 G/s). The software-pipelined variant for small trees keeps 4 (126 VGPRs): a single proof
-// offers 2 waves/SIMD anyway and the tighter budgets spill inside its absorb loop.
+// offers 2 waves/SIMD anyway and the tighter budgets spill inside its absorb loop. The literal form is left to the compiler's own choice
+// (96 / 112 VGPRs, no scratch).
 #ifndef QPGPU_LEAF_WAVES_FUSED
 #define QPGPU_LEAF_WAVES_FUSED 6
 #endif
@@ -86,7 +87,7 @@ static constexpr size_t PAIR_MAX_LEAVES = size_t(1) << 18;   // <= 4 waves/SIMD 
 #define QPGPU_LEAF_WAVES 4
 #endif
 template <bool FUSE, bool FAST>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? QPGPU_LEAF_WAVES_FUSED : QPGPU_LEAF_WAVES, 8))) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? (FUSE ? QPGPU_LEAF_WAVES_FUSED : QPGPU_LEAF_WAVES) : 1, 8))) k_leaves_colmajor(const u64* cols, size_t col_stride, int width, size_t num_leaves, u64* digests,
                                                          u64* level1, u64* level2) {
   __shared__ u64 sm[FUSE ? 256 * 4 : 4];
   size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
