@@ -63,7 +63,7 @@ def pin_to_gpu_numa_node(torch, device_index):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default="W", help="W: the wormhole circuit itself, zk config, 2^14 rows, on the reference's test inputs (default); WN: the same, non-zk, 2^13; "
                     "synthetic shapes — A: leaf non-zk 2^13, B: leaf zk 2^14, V: voting-shaped 2^20, R: recursion-shaped 2^13")

@@ -131,6 +131,8 @@ if __name__ == "__main__":
     path = os.path.join(os.path.dirname(__file__), "..", "zk-circuits_amd", "csrc", "poseidon_fast_dev_constants.h")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_poseidon_fast.py; do not edit. Per constant a: limbs (27, 27, 10 bits) of a, then of a*2^32 mod p.\n#pragma once\n")
+        f.write("// all 360 round constants followed by a row of zeros (what the last round's MDS product has to add), so that 'the constants after round r' is a row for every r\n")
+        f.write("#define QP_POSEIDON_FASTDEV_RC_PAD " + ", ".join("0x%016xULL" % x for x in list(rc) + [0] * 12) + "\n")
         f.write("// round constants of rounds 0-3 followed by FIRST (what the fourth full round's MDS folds in instead of round 4's constants)\n")
         f.write("#define QP_POSEIDON_FASTDEV_RC_HEAD " + ", ".join("0x%016xULL" % x for x in list(rc[:48]) + list(first)) + "\n")
         f.write("#define QP_POSEIDON_FASTDEV_INIT \\\n" + ", \\\n".join("  " + arr32(limbs(x)) for row in init for x in row) + "\n")

@@ -104,6 +104,7 @@ __device__ __constant__ const u64 PFD_Q[22] = {QP_POSEIDON_FAST_Q};
 // Forces the pending scalar loads to have landed here (an empty asm that reads one of the loaded values).
 __device__ __forceinline__ void smem_touch(u32 x) { asm volatile("" :: "s"(x)); }
 __device__ __constant__ const u64 PFD_RC_HEAD[60] = {QP_POSEIDON_FASTDEV_RC_HEAD};
+__device__ __constant__ const u64 PFD_RC_PAD[372] = {QP_POSEIDON_FASTDEV_RC_PAD};
 
 // a*b + c -> lazy residue; a, b, c any u64. The low half of c rides in the first multiply-add; a0*b1 + (p0 >> 32) <= 2^64 - 2^32, so the
 // high half of c (< 2^32) still fits on top of it.
@@ -169,6 +170,41 @@ __device__ __forceinline__ u64 dot11_dev(const u32* __restrict__ c, const u64* x
   return dot_finish(a);
 }
 
+// The same with the twelve constants already in registers. Left alone the compiler sinks each row's scalar load down to its use (twelve
+// exposed scalar-load latencies per round: 28 % of a leaf-hash wave's lifetime parked at s_waitcnt, tools/pmc_wave_stalls.py); the callers below
+// request the whole row block at the top of the round, behind a scheduling barrier, so it arrives while the S-boxes run.
+__device__ __forceinline__ void mds_rc_lazy_pre(u64 st[12], const u64 (&c)[12]) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { lo[i] = (u32)st[i]; hi[i] = (u32)(st[i] >> 32); }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 sl = (u32)c[r], sh = c[r] >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { sl = mad32(lo[(i + r) % 12], C[i], sl); sh = mad32(hi[(i + r) % 12], C[i], sh); }
+    if (r == 0) { sl = mad32(lo[0], 8, sl); sh = mad32(hi[0], 8, sh); }
+    st[r] = mds_row_fold(sl, sh);
+  }
+}
+// One round with its constants one round ahead: `c` (what this round's MDS product adds: the next round's constants) was requested a whole
+// round ago; the request for the round after (`next`, 12 wave-uniform values) goes out first, behind a scheduling barrier, and replaces c.
+template <bool FULL>
+__device__ __forceinline__ void round_pre(u64 st[12], u64 (&c)[12], const u64* __restrict__ next) {
+  u64 n[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) n[i] = next[i];
+  __builtin_amdgcn_sched_barrier(0);
+  st[0] = sbox7_lazy(st[0]);
+  if (FULL) {
+#pragma unroll
+    for (int i = 1; i < 12; i++) st[i] = sbox7_lazy(st[i]);
+  }
+  mds_rc_lazy_pre(st, c);
+#pragma unroll
+  for (int i = 0; i < 12; i++) c[i] = n[i];
+}
+
 // Full permutation on lazy/canonical input; output canonical. FAST selects the form of the 22 partial rounds: the fast form has 7 % fewer
 // instructions (17.75 k against 19.0 k) and wins wherever the chip is full (2.6 against 2.29 G permutations/s saturated); a lone wave per SIMD
 // runs the literal form faster (its round is 472 mostly independent instructions, the fast round a chain S-box -> dot product -> S-box), so
@@ -180,23 +216,19 @@ __device__ __forceinline__ void poseidon_permute_dev_t(u64 st[12]) {
   if constexpr (!FAST) {
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], rc[i]);
-  for (; r < 4; r++) {
+  u64 c[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
-    mds_rc_lazy(st, rc + 12 * (r + 1));
-  }
-  for (; r < 26; r++) {
-    st[0] = sbox7_lazy(st[0]);
-    mds_rc_lazy(st, rc + 12 * (r + 1));
-  }
+  for (int i = 0; i < 12; i++) c[i] = PFD_RC_PAD[12 + i];
+  for (; r < 4; r++) round_pre<true>(st, c, PFD_RC_PAD + 12 * (r + 2));
+  for (; r < 26; r++) round_pre<false>(st, c, PFD_RC_PAD + 12 * (r + 2));
+  for (; r < 30; r++) round_pre<true>(st, c, PFD_RC_PAD + 12 * (r + 2 < 30 ? r + 2 : 30));
   } else {
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], PFD_RC_HEAD[i]);
-  for (; r < 4; r++) {
+  u64 c[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
-    mds_rc_lazy(st, PFD_RC_HEAD + 12 * (r + 1));
-  }
+  for (int i = 0; i < 12; i++) c[i] = PFD_RC_HEAD[12 + i];
+  for (; r < 4; r++) round_pre<true>(st, c, PFD_RC_HEAD + 12 * (r + 2 < 5 ? r + 2 : 4));
   {
     u64 t[11];
 #pragma unroll
@@ -210,17 +242,16 @@ __device__ __forceinline__ void poseidon_permute_dev_t(u64 st[12]) {
   // ahead of its first use, and the scheduling barriers keep the compiler from sinking the requests down to the uses (as it does when
   // left alone: one exposed scalar-load latency per 16 dwords).
   // Chunks of a round's constants: w1 = dot terms 0-3 (24 dwords), w2 = terms 4-7 (24), w3 = terms 8-10 (18), vq = V[t] and Q[t+1] (24).
-  // Request order in time: w1', w2' (during the multiply-adds of the previous round), w3, vq (during this round's dot product): every chunk
-  // is requested two sub-sections ahead of its first use and at most 66 dwords are live at once.
+  // Requests: vq in front of the dot product's second part (used 54 instructions later), w1' in front of the S-box (used a round's
+  // multiply-adds later), w2' and w3' in front of the second half of the multiply-adds; at most 78 dwords are live at once. Every request
+  // follows a dummy use of the previous one, so no wait ever has a fresh request to drain.
   u32 w1[24], w2[24], w3[18];
 #pragma unroll
   for (int k = 0; k < 24; k++) { w1[k] = PFD_WHAT[k]; w2[k] = PFD_WHAT[24 + k]; }
+#pragma unroll
+  for (int k = 0; k < 18; k++) w3[k] = PFD_WHAT[48 + k];
   u64 s0 = sbox7_add_lazy(st[0], PFD_Q[0]);
   for (int t = 0; t < 21; t++) {
-    __builtin_amdgcn_sched_barrier(0);
-    smem_touch(w2[0]);
-#pragma unroll
-    for (int k = 0; k < 18; k++) w3[k] = PFD_WHAT[66 * t + 48 + k];
     __builtin_amdgcn_sched_barrier(0);
     Col3 a = dot_begin(s0);
     dot_terms<4>(a, w1, st + 1);
@@ -231,7 +262,6 @@ __device__ __forceinline__ void poseidon_permute_dev_t(u64 st[12]) {
     for (int j = 0; j < 12; j++) vq[j] = PFD_VQ[12 * t + j];
     __builtin_amdgcn_sched_barrier(0);
     dot_terms<4>(a, w2, st + 5);
-    __builtin_amdgcn_sched_barrier(0);
     dot_terms<3>(a, w3, st + 9);
     const u64 d = dot_finish(a);
     __builtin_amdgcn_sched_barrier(0);
@@ -246,6 +276,8 @@ __device__ __forceinline__ void poseidon_permute_dev_t(u64 st[12]) {
     smem_touch(w1[0]);
 #pragma unroll
     for (int k = 0; k < 24; k++) w2[k] = PFD_WHAT[66 * (t + 1) + 24 + k];
+#pragma unroll
+    for (int k = 0; k < 18; k++) w3[k] = PFD_WHAT[66 * (t + 1) + 48 + k];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 5; j < 11; j++) st[1 + j] = mul_add_lazy_u(s0, vq[j], st[1 + j]);
@@ -256,23 +288,17 @@ __device__ __forceinline__ void poseidon_permute_dev_t(u64 st[12]) {
     Col3 a = dot_begin(s0);
     dot_terms<4>(a, w1, st + 1);
     dot_terms<4>(a, w2, st + 5);
-    dot_terms<3>(a, PFD_WHAT + 66 * 21 + 48, st + 9);
+    dot_terms<3>(a, w3, st + 9);
     st[0] = dot_finish(a);
 #pragma unroll
     for (int j = 0; j < 11; j++) st[1 + j] = mul_add_lazy_u(s0, PFD_VQ[12 * 21 + j], st[1 + j]);
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], rc[12 * 26 + i]);
-  r = 26;
-  }
-  for (; r < 29; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
-    mds_rc_lazy(st, rc + 12 * (r + 1));
+  for (int i = 0; i < 12; i++) c[i] = PFD_RC_PAD[12 * 27 + i];
+  for (r = 26; r < 30; r++) round_pre<true>(st, c, PFD_RC_PAD + 12 * (r + 2 < 30 ? r + 2 : 30));
   }
-#pragma unroll
-  for (int i = 0; i < 12; i++) st[i] = sbox7_lazy(st[i]);
-  mds_rc_lazy(st, nullptr);
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
 }
