@@ -1,14 +1,21 @@
+# End-of-round measurements on the final tree (GPU box, from the repo root): the whole GPU suite, the default bench line with all extras,
+# the other presets, the batch lines, the permutation-rate sweep. Per-config rocprofv3 summaries: tools/profile_round2.sh.
 set -e
-mkdir -p gpurun_out/final
-python -m pytest tests -m gpu -q 2>&1 | tail -2 > gpurun_out/final/pytest_gpu.txt
-python bench.py > gpurun_out/final/bench_B.json 2> gpurun_out/final/bench_B.err
-python bench.py --preset A > gpurun_out/final/bench_A.json 2>/dev/null
-python bench.py --preset R --no-cpu-baseline > gpurun_out/final/bench_R.json 2>/dev/null
-python bench.py --preset V --steps 3 --warmup 1 --no-pipelined > gpurun_out/final/bench_V.json 2>/dev/null
-python bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_B_batch64.json 2>/dev/null
-python tools/permute_rate.py > gpurun_out/final/permute_rate.txt 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipelined > $GRAFT_REPO_ROOT/gpurun_out/final/bench_under_rocprof.json 2>/dev/null
-cp /tmp/pf/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/final/kernel_stats.csv
-python3 $GRAFT_REPO_ROOT/tools/trace_timeline.py /tmp/pf/b_kernel_trace.csv > $GRAFT_REPO_ROOT/gpurun_out/final/timeline_B.txt
+O=gpurun_out/final; mkdir -p $O
+python -m pytest tests -m gpu -q 2>&1 | tail -2 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+python tools/permute_rate.py $O/r02_poseidon_issue_bound.json > $O/permute_rate.txt 2>/dev/null
+python bench.py > $O/bench_W.json 2> $O/bench_W.err
+python bench.py --preset B --no-tree > $O/bench_B.json 2>/dev/null
+python bench.py --preset A --no-tree > $O/bench_A.json 2>/dev/null
+python bench.py --preset WN --no-tree > $O/bench_WN.json 2>/dev/null
+python bench.py --preset V --steps 5 --warmup 1 --no-pipelined --no-tree > $O/bench_V.json 2>/dev/null
+python bench.py --batch 64 --steps 5 --warmup 1 --no-tree > $O/bench_W64.json 2>/dev/null
+python bench.py --preset B --batch 64 --steps 5 --warmup 1 --no-tree > $O/bench_B64.json 2>/dev/null
+python bench.py --preset A --batch 64 --steps 5 --warmup 1 --no-tree > $O/bench_A64.json 2>/dev/null
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/final/bench_*.json")):
+    d = json.loads(open(f).read())
+    print(f.split("/")[-1], d["value"], d["ms_per_step"], (d.get("pipelined") or {}).get("proofs_per_s"), d.get("bit_exact_vs_cpu"), d.get("bit_exact_batch"))
+PY
 echo done

@@ -3,7 +3,7 @@
 
   instructions: static gfx950 ISA of k_permute_batch (hipcc -S of csrc/merkle.hip), per loop, weighted by the trip counts of
                 poseidon_permute_dev (4 full rounds, the dense product in front of the partial rounds, 21 + 1 partial rounds in the
-                fast form, 3 full rounds, 1 unrolled final round);
+                fast form, 4 full rounds);
   costs:        ns per wave-instruction per SIMD at saturation, measured on MI355X by tools/ubench/valu_rates2.hip
                 (profiles/r02_valu_issue_rates2.txt, column wps=8 "(ns)");
   bound:        (a) in cycles: a wave64 instruction occupies its SIMD for 2 cycles if the table shows it at the full rate (v_mov_b32, v_add_u32,
@@ -58,15 +58,15 @@ def main():
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
     # the three round loops of poseidon_permute_dev, in program order: full rounds 0-3 (4 trips), the fast partial rounds (21 trips; the
-    # 22nd is peeled behind the loop) and full rounds 26-28 (3 trips); everything between and around them runs once
+    # 22nd is peeled behind the loop) and full rounds 26-29 (4 trips); everything between and around them runs once
     heads = [(i, re.match(r"^(\.LBB\d+_\d+):", l).group(1)) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:.*Loop Header", l)]
     assert len(heads) == 3, "expected the three round loops of poseidon_permute_dev"
     spans = []
     for i, lab in heads:
         back = next(j for j in range(i, len(body)) if re.search(r"s_cbranch_scc[01]\s+" + re.escape(lab) + r"\b", body[j]))
         spans.append((i, back + 1))
-    names = [("full rounds 0-3", 4), ("partial rounds (fast form)", 21), ("full rounds 26-28", 3)]
-    between = ["prologue (load, first constants)", "dense 11x11 product + first S-box", "last partial round + constants of round 26", "final round + store"]
+    names = [("full rounds 0-3", 4), ("partial rounds (fast form)", 21), ("full rounds 26-29", 4)]
+    between = ["prologue (load, first constants)", "dense 11x11 product + first S-box", "last partial round + constants of round 26", "canonical form + store"]
     segs, pos = [], 0
     for k, (a, b) in enumerate(spans):
         segs.append((between[k], pos, a, 1)); segs.append((names[k][0], a, b, names[k][1])); pos = b

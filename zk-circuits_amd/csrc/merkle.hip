@@ -76,12 +76,11 @@ void poseidon_permute_batch(u64* states, size_t count, hipStream_t s, int form) 
 // (measured on MI355X: at N = 2^17 all 512 blocks run in lockstep, so the fused tail costs two more permutation
 // latencies at half/quarter occupancy and the leaf+levels total gets 5 % WORSE; profiles/r01 notes). Enabled from 2^20 leaves.
 static constexpr size_t PAIR_MAX_LEAVES = size_t(1) << 18;   // <= 4 waves/SIMD per-lane: the pair form fills the chip better
-// Occupancy targets (tools/ab_leaf_waves.sh on MI355X, V = 2^23 leaves, launch average): 3 waves/SIMD 30.6 ms, 4: 29.0, 5: 28.9, 6: 27.2 (80 VGPRs,
-// the saturated rate of the permutation, 2.6 G/s). The software-pipelined variant for small trees keeps 4 (126 VGPRs): a single proof
-// offers 2 waves/SIMD anyway and the tighter budgets spill inside its absorb loop. The literal form is left to the compiler's own choice
-// (96 / 112 VGPRs, no scratch).
+// Occupancy floor of the fast-form kernels (tools/ab_leaf_waves.sh on MI355X, same box; V = 2^23 leaves launch average / single W proof): floor
+// 4 waves/SIMD 27.64 ms / 273.0 proofs/s, 5: 27.58 / 270.8, 6: 28.09 / 268.6 (the tighter budgets spill into scratch). With the floor at 4 the
+// compiler settles at 81-100 VGPRs without scratch, i.e. 5-6 resident waves. The literal form is left to the compiler's own choice.
 #ifndef QPGPU_LEAF_WAVES_FUSED
-#define QPGPU_LEAF_WAVES_FUSED 6
+#define QPGPU_LEAF_WAVES_FUSED 4
 #endif
 #ifndef QPGPU_LEAF_WAVES
 #define QPGPU_LEAF_WAVES 4
