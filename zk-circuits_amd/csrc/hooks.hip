@@ -25,7 +25,7 @@ extern "C" {
 int qpgpu_test_permute(uint64_t* states, size_t count) { return qpgpu_test_permute_form(states, count, -1); }
 // form: 0 literal partial rounds, 1 fast partial rounds, -1 the library's default
 int qpgpu_test_permute_form(uint64_t* states, size_t count, int form) {
-  if (!states || form < -1 || form > 1) return set_err(-1, "bad argument");
+  if (!states || form < -1 || form > 3) return set_err(-1, "bad argument");
   DevBuf d; HOOK_CHECK(d.alloc(count * 96));
   HOOK_CHECK(hipMemcpy(d.p, states, count * 96, hipMemcpyHostToDevice));
   poseidon_permute_batch(d.u(), count, 0, form);

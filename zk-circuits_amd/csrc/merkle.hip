@@ -52,9 +52,11 @@ void publish_to_host(const u64* src, u64* dst_mapped, size_t words, u64* flag_ma
   hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, src, dst_mapped, words, flag_mapped, counter_dev, seq, extra, clear_extra ? 1 : 0);
 }
 
-template <bool FAST>
+// HALF: only the even lanes of every wave work (experiment: does a half-empty wave64 issue faster? it does not — profiles/r02 notes)
+template <bool FAST, bool HALF = false>
 __global__ void k_permute_batch(u64* states, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (HALF) { if (i & 1) return; i >>= 1; }
   if (i >= count) return;
   u64 st[12];
 #pragma unroll
@@ -67,6 +69,8 @@ __global__ void k_permute_batch(u64* states, size_t count) {
 void poseidon_permute_batch(u64* states, size_t count, hipStream_t s, int form) {
   if (!count) return;
   if (form < 0) form = opts().poseidon_fast != 0;
+  if (form == 2) { hipLaunchKernelGGL((k_permute_batch<false, true>), dim3((unsigned)((2 * count + 255) / 256)), dim3(256), 0, s, states, count); return; }
+  if (form == 3) { hipLaunchKernelGGL((k_permute_batch<true, true>), dim3((unsigned)((2 * count + 255) / 256)), dim3(256), 0, s, states, count); return; }
   if (form) hipLaunchKernelGGL(k_permute_batch<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
   else hipLaunchKernelGGL(k_permute_batch<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
 }
