@@ -96,15 +96,15 @@ __device__ __forceinline__ void mds_rc_lazy(u64 st[12], const u64* __restrict__ 
 // with full 64-bit constants. What makes that cheaper here: the dot product takes each constant a as 27/27/10-bit limbs of a and of
 // a' = a*2^32 (mod p), so a*x = a*x_lo + a'*x_hi is six 32x32 multiply-adds into three column sums that cannot overflow (22 terms < 2^59
 // each), with ONE recombination per dot product instead of a reduction per term: ~80 instructions per dot, ~16 per multiply-add,
-// ~314 per round against 472 (static counts: tools/poseidon_issue_bound.py).
-__device__ __constant__ const u32 PFD_INIT[11 * 11 * 6] = {QP_POSEIDON_FASTDEV_INIT};
-__device__ __constant__ const u32 PFD_WHAT[22 * 11 * 6] = {QP_POSEIDON_FASTDEV_WHAT};
-__device__ __constant__ const u64 PFD_VQ[22 * 12] = {QP_POSEIDON_FASTDEV_VQ};
+// 366 per round against 472 (static counts: tools/poseidon_issue_bound.py).
+__device__ __constant__ const u32 PFD_INIT[11 * 11 * 6] = {QP_POSEIDON_FASTDEV_INIT};     // dense product in front of the partial rounds (limbs)
+__device__ __constant__ const u32 PFD_WHAT[22 * 11 * 6] = {QP_POSEIDON_FASTDEV_WHAT};     // per round: the dot product's eleven constants (limbs)
+__device__ __constant__ const u64 PFD_VQ[22 * 12] = {QP_POSEIDON_FASTDEV_VQ};             // per round: the eleven multipliers, then the next S-box's constant
 __device__ __constant__ const u64 PFD_Q[22] = {QP_POSEIDON_FAST_Q};
+__device__ __constant__ const u64 PFD_RC_HEAD[60] = {QP_POSEIDON_FASTDEV_RC_HEAD};        // constants of rounds 0-3, then what follows the fourth round
+__device__ __constant__ const u64 PFD_RC_PAD[372] = {QP_POSEIDON_FASTDEV_RC_PAD};         // all round constants, then a row of zeros
 // Forces the pending scalar loads to have landed here (an empty asm that reads one of the loaded values).
 __device__ __forceinline__ void smem_touch(u32 x) { asm volatile("" :: "s"(x)); }
-__device__ __constant__ const u64 PFD_RC_HEAD[60] = {QP_POSEIDON_FASTDEV_RC_HEAD};
-__device__ __constant__ const u64 PFD_RC_PAD[372] = {QP_POSEIDON_FASTDEV_RC_PAD};
 
 // a*b + c -> lazy residue; a, b, c any u64. The low half of c rides in the first multiply-add; a0*b1 + (p0 >> 32) <= 2^64 - 2^32, so the
 // high half of c (< 2^32) still fits on top of it.
