@@ -187,6 +187,36 @@ def test_host_transcript_permutation_fast_form_equals_literal_form():
     assert [int(x) for x in s[:4]] == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47, 0xd40285597c6a8825, 0x613a4f81e81231d2]
 
 
+def test_device_fast_round_tables_are_the_host_tables_in_limb_form():
+    """csrc/poseidon_fast_dev_constants.h (what the leaf-hash kernels read) against csrc/poseidon_fast_constants.h (the host transcript's tables,
+    checked against the literal permutation above) and the round constants: every dot-product constant a appears as the 27/27/10-bit limbs of a and
+    of a * 2^32 mod p with a nonzero low limb (poseidon_dev.h's dot_finish relies on it), VQ is V[t] followed by Q[t+1], RC_PAD the 360 round
+    constants followed by twelve zeros, RC_HEAD rounds 0-3 followed by FIRST. A stale generated header fails here, not on the GPU box."""
+    import re
+    csrc = os.path.join(ROOT, "zk-circuits_amd", "csrc")
+    def macros(path):
+        txt = open(path).read().replace("\\\n", " ")
+        return {m.group(1): [int(x.rstrip("uUlL"), 16) for x in re.findall(r"0x[0-9a-fA-F]+[uUlL]*", m.group(2))]
+                for m in re.finditer(r"#define (\w+) (.*)", txt)}
+    host, dev, rc = macros(os.path.join(csrc, "poseidon_fast_constants.h")), macros(os.path.join(csrc, "poseidon_fast_dev_constants.h")), macros(os.path.join(csrc, "poseidon_constants.h"))
+    rcs = next(v for v in rc.values() if len(v) == 360)
+    def limbs(a):
+        out = []
+        for v in (a, a * (1 << 32) % P):
+            out += [v & 0x7FFFFFF, (v >> 27) & 0x7FFFFFF, v >> 54]
+        return out
+    init, what, V, Q, first = host["QP_POSEIDON_FAST_INIT"], host["QP_POSEIDON_FAST_WHAT"], host["QP_POSEIDON_FAST_V"], host["QP_POSEIDON_FAST_Q"], host["QP_POSEIDON_FAST_FIRST"]
+    assert len(init) == 121 and len(what) == 242 and len(V) == 242 and len(Q) == 22 and len(first) == 12
+    assert dev["QP_POSEIDON_FASTDEV_INIT"] == [l for a in init for l in limbs(a)]
+    assert dev["QP_POSEIDON_FASTDEV_WHAT"] == [l for a in what for l in limbs(a)]
+    for tab in ("QP_POSEIDON_FASTDEV_INIT", "QP_POSEIDON_FASTDEV_WHAT"):
+        t = dev[tab]
+        assert all(t[i] >= 1 for i in range(0, len(t), 3)) and all(t[i + 2] < 1024 for i in range(0, len(t), 3))
+    assert dev["QP_POSEIDON_FASTDEV_VQ"] == [x for t in range(22) for x in V[11 * t:11 * t + 11] + [Q[t + 1] if t < 21 else 0]]
+    assert dev["QP_POSEIDON_FASTDEV_RC_PAD"] == rcs + [0] * 12
+    assert dev["QP_POSEIDON_FASTDEV_RC_HEAD"] == rcs[:48] + first
+
+
 def test_salt_stream_is_chacha8():
     """csrc/salt.h: key-derived salts are the ChaCha8 keystream (DJB layout: 64-bit block counter, 64-bit nonce), eight u64 per block,
     each taken mod p by one conditional subtraction. Known answer: the all-zero key/nonce/counter block of the ChaCha8 test vectors
