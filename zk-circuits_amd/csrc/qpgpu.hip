@@ -616,13 +616,14 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
   // ---- 1/2: witness in, wires commitment
   const u64* wires_vals = (const u64*)wires;
   if (!(opts && opts->wires_on_device)) { HIP_TRY(hipMemcpyAsync(w->wires_vals, wires, (size_t)c->W * n * 8, hipMemcpyHostToDevice, s)); wires_vals = w->wires_vals; }
+  (void)hipEventRecord(w->ev_in, s);                                  // the wires are on the device
+  values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);        // the critical path's first kernels go out first
   // A wire >= p would flow through the lazy arithmetic and be copied raw into query rows: the whole matrix is checked on the device, on
   // the side stream (the wires are read-only), and the flag is collected with the proof's last hand-off — before any byte is released.
-  (void)hipEventRecord(w->ev_in, s); (void)hipStreamWaitEvent(w->side, w->ev_in, 0);
+  (void)hipStreamWaitEvent(w->side, w->ev_in, 0);
   check_canonical(wires_vals, (size_t)c->W * n, w->pow_result + 1, w->side);
   (void)hipEventRecord(w->ev_canon, w->side);
   u64 pi_hash[4]; hash_no_pad((const u64*)pis, d.num_public_inputs, pi_hash);
-  values_to_coeffs(c, w, wires_vals, c->W, w->wires_lde, w->wires_coeffs, s);
   const bool split = c->split_quotient && !w->batch_mode;
   const bool split_serial = qp::opts().split_serial != 0;
   commit_coeffs(c, w, w->wires_coeffs, c->W, w->wires_lde, w->wires_dig, 1, salt, s, [&] {
