@@ -205,8 +205,8 @@ __device__ __forceinline__ void round_pre(u64 st[12], u64 (&c)[12], const u64* _
   for (int i = 0; i < 12; i++) c[i] = n[i];
 }
 
-// Full permutation on lazy/canonical input; output canonical. FAST selects the form of the 22 partial rounds: the fast form has 7 % fewer
-// instructions (17.75 k against 19.0 k) and wins wherever the chip is full (2.6 against 2.29 G permutations/s saturated); a lone wave per SIMD
+// Full permutation on lazy/canonical input; output canonical. FAST selects the form of the 22 partial rounds: the fast form has 8 % fewer
+// instructions (18.1 k against 19.7 k) and wins wherever the chip is full (2.6 against 2.29 G permutations/s saturated); a lone wave per SIMD
 // runs the literal form faster (its round is 472 mostly independent instructions, the fast round a chain S-box -> dot product -> S-box), so
 // the latency-bound stages keep it.
 template <bool FAST>
