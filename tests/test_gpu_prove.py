@@ -255,6 +255,22 @@ def test_split_quotient_path_matches_oracle(monkeypatch, mode):
             gc.close()
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_both_forms_of_the_leaf_hash_partial_rounds_give_the_oracle_bytes(monkeypatch, form):
+    """QPGPU_POSEIDON_FAST=0 / 1 force the literal / the fast form of the permutation's 22 partial rounds in every leaf-hash launch (the default
+    picks by tree size and batch mode): same proof bytes, single and batched, zk and not — trees from 2^9 to 2^17 leaves."""
+    monkeypatch.setenv("QPGPU_POSEIDON_FAST", form)
+    for preset in ("T", "TZ", "A", "B"):
+        sc = SynthCircuit(preset); oc = OracleCircuit(sc.desc); gc = GpuCircuit(sc.desc)     # env is read at circuit creation
+        try:
+            w, p = sc.witness(33)
+            want = oc.prove(w, p, sc.salts(33) if sc.desc.zero_knowledge else None)
+            assert first_diff(gc.prove(w, p, salt_seed=33), want) is None
+            assert first_diff(gc.prove_batch([w, w], [p, p], salt_seed=33)[0], want) is None
+        finally:
+            gc.close()
+
+
 def test_recursion_gate_violation_is_caught_downstream(circuits):
     """A broken recursion-gate row still yields bytes (as upstream), identical to the oracle's, and the verifier rejects them."""
     sc, oc, gc = circuits("RT")
