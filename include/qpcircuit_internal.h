@@ -14,6 +14,23 @@ extern "C" {
 int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, uint32_t num_inputs, uint32_t num_ops, qpc_circuit** out, uint64_t* inputs,
                             uint64_t* expected, size_t cap, size_t* num_outputs);
 
+/* ---- hint-soundness mutation sweep (zk-circuits_amd/circuit/mutation.cc). A circuit's HINTS are the values its witness generator
+ * supplies instead of a gate computing them: inverses (kind 2), BaseSum limbs (3), extension-field inverses (5), 32-bit halves (6) — the
+ * kind numbers are the builder's operation kinds; kind 100 = an input target flipped after generation. For hint (or input) number
+ * first, first + step, ... and each mode selected by `modes_mask` the sweep substitutes another value, re-derives every later value
+ * (input flips: nothing), writes the wire matrix and calls `check` with it and the rows that differ from the honest matrix (`full` != 0
+ * on every `full_every`-th call: the callee should then check the whole matrix, copy constraints included). check returns 0 = the witness
+ * satisfies the circuit, > 0 = it does not, < 0 = abort. Verdicts: 0 killed (check rejected), 1 benign (accepted, no value other than the
+ * hint's own moved, same public inputs), 2 SURVIVED (accepted although other values moved: under-constrained), 3 inconsistent (generators
+ * disagreed on a class yet check accepted), 4 skipped (the mode does not apply to this value), 5 no cell carries the value,
+ * 6 blocked (the value is copy-tied to a class that is already fixed; the matrix did not move). */
+typedef struct { uint32_t index, kind, mode, verdict; uint64_t conflicts, changed_classes, rows; } qpc_mutation_result;
+typedef int (*qpc_witness_check_fn)(void* ctx, const uint64_t* wires, const uint64_t* public_inputs, const uint32_t* rows, size_t num_rows, int full);
+size_t qpc_circuit_num_hints(const qpc_circuit* c);
+int qpc_mutation_sweep(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint32_t what /* 0 hints, 1 input flips */,
+                       size_t first, size_t step, uint32_t modes_mask, uint64_t seed, uint32_t full_every, qpc_witness_check_fn check, void* ctx,
+                       qpc_mutation_result* out, size_t cap, size_t* count);
+
 #ifdef __cplusplus
 }
 #endif

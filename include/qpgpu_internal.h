@@ -32,6 +32,13 @@ int qpgpu_profile_get(int id, uint64_t* launches, double* ms, double* alg_bytes)
 /* stage boundaries of the calling thread's last proof when QPGPU_TIMING=1 was set at context creation */
 int qpgpu_last_stage_ms(double* out, int cap);
 
+/* Host cores the library sizes its thread pools and hand-off wait mode for (csrc/hostcpus.h): affinity mask, capped by the cgroup CPU quota,
+ * divided by LOCAL_WORLD_SIZE; re-evaluated on every call (the library itself caches its first reading). */
+int qpgpu_usable_host_cpus(void);
+/* Hand-offs (device -> host transcript) of this process that fell back from the publish kernel + flag to copy + stream synchronise
+ * because the flag did not arrive. Expected 0; bench.py prints it. */
+uint64_t qpgpu_handoff_fallbacks(void);
+
 /* ---- 3. kernel test hooks */
 int qpgpu_test_permute(uint64_t* states /*[count][12]*/, size_t count);
 int qpgpu_test_permute_form(uint64_t* states /*[count][12]*/, size_t count, int form /* 0 literal, 1 fast partial rounds, -1 default */);

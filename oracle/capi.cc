@@ -184,6 +184,23 @@ int orc_check_witness(void* h, const u64* wires, const u64* public_inputs) {
   if (num != den) return fail("copy constraints violated (grand product != 1)");
   return 0;
 }
+// Gate constraints on the listed rows only (the hint-soundness sweep hands over the rows that differ from a matrix that passed
+// orc_check_witness: unchanged rows evaluate as they did). 0 = every constraint of every listed row is zero.
+int orc_check_witness_rows(void* h, const u64* wires, const u64* public_inputs, const uint32_t* rows, size_t num_rows) {
+  auto* oc = (OrcCircuit*)h; const Common& c = oc->common; size_t n = c.n();
+  Hash pih = hash_no_pad(public_inputs, c.num_public_inputs);
+  FB pi[4] = {FB(pih[0]), FB(pih[1]), FB(pih[2]), FB(pih[3])};
+  std::vector<FB> consts(c.num_constants), w(c.num_wires), out(c.num_gate_constraints);
+  for (size_t r = 0; r < num_rows; r++) {
+    const size_t i = rows[r];
+    if (i >= n) return fail("row out of range");
+    for (int k = 0; k < c.num_constants; k++) consts[k] = FB(oc->constants_sigmas[(size_t)k * n + i]);
+    for (int k = 0; k < c.num_wires; k++) w[k] = FB(wires[(size_t)k * n + i]);
+    eval_gate_constraints<FB>(c, consts.data(), w.data(), pi, out.data());
+    for (int k = 0; k < c.num_gate_constraints; k++) if (out[k].v != 0) return fail("gate constraint " + std::to_string(k) + " nonzero at row " + std::to_string(i));
+  }
+  return 0;
+}
 int orc_max_threads() { return omp_get_max_threads(); }
 
 } // extern "C"

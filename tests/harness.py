@@ -50,3 +50,40 @@ def bitrev_indices(log_n):
     for b in range(log_n):
         r |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(log_n - 1 - b)
     return r.astype(np.int64)
+
+
+def keyed_salts(key, stream, N):
+    """The [3][4][N] salt columns of a zk proof under (32-byte key, stream): ChaCha8 keystream of csrc/salt.h in numpy, for ANY N
+    (SynthCircuit.salts_keyed only serves its own circuit's N). Element index = (oracle*4 + column)*N + leaf, eight elements per block."""
+    key = bytes(key)
+    assert len(key) == 32 and (12 * N) % 8 == 0
+    nblk = 12 * N // 8
+    k = np.frombuffer(key, dtype="<u4").astype(np.uint32)
+    blk = np.arange(nblk, dtype=np.uint64)
+    s = np.empty((16, nblk), dtype=np.uint32)
+    for i, c in enumerate((0x61707865, 0x3320646e, 0x79622d32, 0x6b206574)):
+        s[i] = c
+    for i in range(8):
+        s[4 + i] = k[i]
+    s[12] = (blk & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    s[13] = (blk >> np.uint64(32)).astype(np.uint32)
+    s[14] = np.uint32(stream & 0xFFFFFFFF)
+    s[15] = np.uint32((stream >> 32) & 0xFFFFFFFF)
+    x = s.copy()
+
+    def rotl(v, r):
+        return (v << np.uint32(r)) | (v >> np.uint32(32 - r))
+
+    def qr(a, b, c, d):
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16)
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12)
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8)
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7)
+    with np.errstate(over="ignore"):
+        for _ in range(4):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        x += s
+    z = x[0::2].astype(np.uint64) | (x[1::2].astype(np.uint64) << np.uint64(32))          # [8][nblk]
+    z = np.where(z >= np.uint64(P), z - np.uint64(P), z)
+    return np.ascontiguousarray(z.T).reshape(3, 4, N)

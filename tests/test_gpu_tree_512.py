@@ -1,0 +1,144 @@
+"""BASELINE configs[3] at full size on one GPU (`-m gpu`): 512 zero-knowledge wormhole leaf proofs from CircuitInputs -> 511 node proofs over
+nine levels of recursive verifier circuits -> one root proof. Mirrors wormhole/aggregator/benches/aggregator.rs:107-130 (aggregate_proofs_2_9
+would be its (b, d) = (2, 9) line) and wormhole/aggregator/src/circuits/tree.rs:56-103; the eight-GPU sharding of the same tree is rehearsed
+with two gloo ranks sharing the device (tree.rs:100's par_chunks becomes ranks)."""
+import importlib
+import os
+import subprocess
+import sys
+import textwrap
+import numpy as np
+import pytest
+from harness import OracleCircuit, TEST_SALT_KEY, keyed_salts, ROOT
+
+pkg = importlib.import_module("zk-circuits_amd")
+aggregator = importlib.import_module("zk-circuits_amd.aggregator")
+th = pkg.test_helpers
+pytestmark = pytest.mark.gpu
+
+SEED = 0x512
+
+
+def _inputs(n):
+    out = []
+    for i in range(n):
+        ci = th.circuit_test_inputs()
+        ci.public.exit_account = pkg.BytesDigest(int(i + 1).to_bytes(8, "little") + bytes(24))      # leaf i pays account i + 1
+        out.append(ci)
+    return out
+
+
+class _Recording:
+    """A chunk prover that keeps what every level consumed and produced (the tree only hands back the root)."""
+    takes_first_index = True
+
+    def __init__(self, inner):
+        self.inner, self.levels = inner, {}
+
+    def prove_chunks(self, chunks, level, first_index=0):
+        out = self.inner.prove_chunks(chunks, level, first_index)
+        self.levels[level] = (chunks, out)
+        return out
+
+    def __call__(self, chunk, level):
+        return self.prove_chunks([chunk], level)[0]
+
+
+def test_configs3_512_leaves_nine_levels_one_gpu():
+    n, depth = 512, 9
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+    assert cd.desc.degree_bits == 14 and cd.desc.zero_knowledge == 1 and cd.proof_size == 148932          # the shape of bench-data/proof.bin
+    rec = _Recording(pkg.RecursiveChunkProver(cd, salt_seed=SEED))
+    agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, depth), rec)
+    inputs = _inputs(n)
+    agg.prove_leaves(inputs, salt_seed=SEED)
+    leaves = list(agg.proofs_buffer)
+    assert len(leaves) == n and len(agg._witness_pool) <= agg.GROUP * agg.RING_GROUPS                    # bounded witness ring
+    root = agg.aggregate()
+    assert sorted(rec.levels) == list(range(depth))
+    assert [len(rec.levels[l][1]) for l in range(depth)] == [256 >> l for l in range(depth)]            # 511 nodes
+    assert all(len(v) <= rec.inner.GROUP * rec.inner.RING_GROUPS for v in rec.inner._pool.values())
+
+    # ---- the root: accepted by the product verifier and by the oracle verifier; its public inputs are the 512 leaves' in order
+    rcd = root.circuit_data
+    assert rcd.desc.num_public_inputs == 16 * n and rcd.desc.zero_knowledge == 1                        # zk leaves, zk nodes (tree.rs:111)
+    pkg.WormholeVerifier.new(None, circuit_data=rcd).verify(root.proof)
+    assert OracleCircuit(rcd.desc).verify(root.proof.to_bytes()) is None
+    assert root.proof.public_inputs == [x for p in leaves for x in p.public_inputs]
+    got = agg.extract_leaf_public_inputs(root.proof)
+    assert len(got) == n and all(int.from_bytes(bytes(l.exit_account[:8]), "little") == i + 1 for i, l in enumerate(got))
+    bad = bytearray(root.proof.to_bytes()); bad[-8 * 16 * n + 3] ^= 1                                    # a forged leaf public input
+    with pytest.raises(RuntimeError, match="verification failed"):
+        pkg.WormholeVerifier.new(None, circuit_data=rcd).verify(pkg.ProofWithPublicInputs(bytes(bad), 16 * n))
+
+    # ---- first and last leaf byte-equal to the oracle prover on the same witness, blinding rows and salts
+    built, oc = cd._built, OracleCircuit(cd.desc)
+    for i in (0, n - 1):
+        w, p = built.witness(inputs[i].fill_targets(built.kind), aggregator.proof_blinding_key(SEED, i))
+        assert leaves[i].to_bytes() == oc.prove(w, p, salts=keyed_salts(TEST_SALT_KEY, SEED + i, cd.n << 3)), "leaf %d" % i
+    assert oc.verify(leaves[n // 2].to_bytes()) is None
+
+    # ---- one node per level byte-equal to the oracle prover (the last node of the level: first_index bookkeeping included)
+    for level in range(depth):
+        chunks, out = rec.levels[level]
+        j = len(chunks) - 1
+        ncd, _inner, cap, digest = rec.inner.level(level, 2)
+        node = ncd._built
+        seed = SEED + (level << 20)
+        raw = [c.to_bytes() if hasattr(c, "to_bytes") else bytes(c) for c in chunks[j]]
+        w, p = node.witness(node.aggregation_targets(cap, digest, raw), aggregator.proof_blinding_key(seed, j, b"node"))
+        on = OracleCircuit(ncd.desc)
+        want = on.prove(w, p, salts=keyed_salts(TEST_SALT_KEY, seed + j, ncd.n << 3))
+        assert out[j].proof.to_bytes() == want, "level %d node %d" % (level, j)
+        assert on.verify(out[0].proof.to_bytes()) is None
+    agg.close()
+
+
+def test_two_ranks_sharing_the_gpu_build_the_same_tree(tmp_path):
+    """The N > 1 control flow of configs[3] with REAL node circuits on the device: two gloo ranks share GPU 0, each proves its half of 16
+    zk leaves and its local levels, the top level is dealt out after a blob gather; every rank's root is byte-identical to the
+    single-process root of the same leaves (seeded blinding rows and salts), which the product verifier accepts."""
+    script = tmp_path / "t.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r)
+        import torch
+        torch.cuda.init()
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        pkg = importlib.import_module("zk-circuits_amd"); th = pkg.test_helpers
+        agg_mod = importlib.import_module("zk-circuits_amd.aggregator")
+        SEED, n, depth = 77, 16, 4
+        cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+        cfg = pkg.TreeAggregationConfig(2, depth)
+        ins = []
+        for i in range(n):
+            ci = th.circuit_test_inputs(); ci.public.exit_account = pkg.BytesDigest(int(i + 1).to_bytes(8, "little") + bytes(24)); ins.append(ci)
+        per = n // world
+        prover = pkg.RecursiveChunkProver(cd, salt_seed=SEED)
+        mine = pkg.WormholeProofAggregator(cd, cfg)
+        mine.prove_leaves(ins[rank * per:(rank + 1) * per], salt_seed=SEED + rank * per)
+        local = [p.to_bytes() for p in mine.proofs_buffer]
+        root = agg_mod.aggregate_to_tree_distributed(local, cfg, prover, lambda lvl: prover.proof_size_of_level(lvl))
+        rb = bytes(root.proof.to_bytes() if hasattr(root.proof, "to_bytes") else root.proof)
+        if rank == 0:                                                # the single-process tree over the same leaves
+            solo = pkg.WormholeProofAggregator(cd, cfg, pkg.RecursiveChunkProver(cd, salt_seed=SEED))
+            solo.prove_leaves(ins, salt_seed=SEED)
+            assert [p.to_bytes() for p in solo.proofs_buffer[:per]] == local
+            want = solo.aggregate()
+            assert want.proof.to_bytes() == rb, "distributed root differs from the single-process root"
+            pkg.WormholeVerifier.new(None, circuit_data=want.circuit_data).verify(want.proof)
+            got = solo.extract_leaf_public_inputs(want.proof)
+            assert [int.from_bytes(bytes(l.exit_account[:8]), "little") for l in got] == list(range(1, n + 1))
+        blobs = [None] * world
+        dist.all_gather_object(blobs, rb)
+        assert all(b == blobs[0] for b in blobs)                     # every rank returns the root
+        dist.barrier(); dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29652", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2

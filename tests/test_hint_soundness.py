@@ -1,0 +1,154 @@
+"""Hint-soundness mutation tests for the circuits this repo authored (CPU; the oracle is the checker).
+
+A witness generator HINTS some values instead of deriving them through a gate: inverses (is_equal, barycentric folds), extension-field
+inverses, 32-bit halves (canonical index decomposition), BaseSum limbs. Each must be pinned by constraints, or a dishonest prover picks it
+freely — in the aggregation node that would be a forgeable aggregate (the statement to hold: a node verifies its children,
+/root/reference/wormhole/aggregator/src/circuits/tree.rs:117-121; for the leaf circuit the checks of wormhole/circuit/src/*.rs).
+
+For EVERY hint of a circuit and every mutation mode libqpcircuit's sweep (zk-circuits_amd/circuit/mutation.cc) substitutes another value,
+re-derives everything downstream and hands the wire matrix to the ORACLE's gate-constraint check; sampled mutations get the oracle's
+full check (every row + copy constraints). Allowed outcomes: killed, blocked by a copy constraint, or benign (nothing but the hint's own
+cell moved and the public inputs are unchanged — e.g. is_equal's inverse when the difference is zero). A survivor fails the test.
+Second sweep: every input target flipped AFTER generation with nothing re-derived must be rejected."""
+import collections
+import ctypes
+import os
+import numpy as np
+import pytest
+from harness import (BuiltCircuit, OracleCircuit, ReferenceCircuitShape, check_witness, circuit_lib, oracle, ptr, u64p,
+                     QPC_WORMHOLE, QPC_NULLIFIER, QPC_UNSPENDABLE_ACCOUNT, QPC_STORAGE_PROOF, QPC_VOTE)
+import importlib
+
+pkg = importlib.import_module("zk-circuits_amd")
+th = pkg.test_helpers
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+KINDS = {2: "inverse", 3: "base-sum limbs", 5: "extension inverse", 6: "lo/hi halves", 100: "input flip"}
+VERDICTS = {0: "killed", 1: "benign", 2: "SURVIVED", 3: "INCONSISTENT", 4: "skipped", 5: "no cell", 6: "blocked"}
+
+
+class MutationResult(ctypes.Structure):
+    _fields_ = [("index", ctypes.c_uint32), ("kind", ctypes.c_uint32), ("mode", ctypes.c_uint32), ("verdict", ctypes.c_uint32),
+                ("conflicts", ctypes.c_uint64), ("changed_classes", ctypes.c_uint64), ("rows", ctypes.c_uint64)]
+
+
+CHECK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+
+
+def sweep(circuit, inputs, what, step=1, first=0, modes=0xFF, full_every=97, blinding_key=None, cap=200000):
+    """Runs the sweep with the oracle as checker. Returns (results, stats)."""
+    L, O = circuit_lib(), oracle()
+    L.qpc_circuit_num_hints.restype = ctypes.c_size_t
+    L.qpc_circuit_num_hints.argtypes = [ctypes.c_void_p]
+    L.qpc_mutation_sweep.argtypes = [ctypes.c_void_p, u64p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t,
+                                     ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, CHECK_FN, ctypes.c_void_p, ctypes.POINTER(MutationResult),
+                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    O.orc_check_witness.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    O.orc_check_witness_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    oc = OracleCircuit(circuit.desc)
+    stats = {"calls": 0, "full": 0, "disagree": 0}
+
+    def cb(_ctx, wires, pis, rows, nrows, full):
+        stats["calls"] += 1
+        if nrows == 0:                                        # the honest matrix: the whole check
+            return 0 if O.orc_check_witness(oc.h, wires, pis) == 0 else 1
+        rc = O.orc_check_witness_rows(oc.h, wires, pis, rows, nrows)
+        if full:                                              # sampled: the rows shortcut must agree with the check of every row + copy constraints
+            stats["full"] += 1
+            if (O.orc_check_witness(oc.h, wires, pis) == 0) != (rc == 0):
+                stats["disagree"] += 1
+                return -1
+        return 0 if rc == 0 else 1
+    fn = CHECK_FN(cb)
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+    out = (MutationResult * cap)()
+    count = ctypes.c_size_t()
+    rc = L.qpc_mutation_sweep(circuit.handle, ptr(inputs), len(inputs), None if blinding_key is None else bytes(blinding_key), what, first, step,
+                              modes, 0x5157C0DE, full_every, fn, None, out, cap, ctypes.byref(count))
+    assert rc == 0, L.qpc_last_error().decode()
+    assert stats["disagree"] == 0
+    return [out[i] for i in range(count.value)], stats
+
+
+def summarize(results):
+    table = collections.Counter((KINDS.get(r.kind, r.kind), VERDICTS[r.verdict]) for r in results)
+    return dict(table)
+
+
+def assert_sound(results, name, min_hints=1):
+    bad = [(r.index, KINDS.get(r.kind, r.kind), r.mode, VERDICTS[r.verdict], int(r.changed_classes)) for r in results if r.verdict in (2, 3)]
+    table = summarize(results)
+    hints = len({r.index for r in results})
+    killed = sum(1 for r in results if r.verdict in (0, 6))
+    print("\n%s: %d hints / %d mutations / %d killed or blocked / %d benign / %d skipped / %d survivors  %s"
+          % (name, hints, len(results), killed, sum(r.verdict == 1 for r in results), sum(r.verdict in (4, 5) for r in results), len(bad), table))
+    assert not bad, "%s: under-constrained hints (index, kind, mode, verdict, other values moved): %r" % (name, bad[:20])
+    assert hints >= min_hints
+    return table
+
+
+def _wormhole_inputs(kind):
+    return th.circuit_test_inputs().fill_targets(kind)
+
+
+@pytest.mark.parametrize("kind,name,min_hints", [(QPC_NULLIFIER, "nullifier", 10), (QPC_UNSPENDABLE_ACCOUNT, "unspendable account", 2),
+                                                 (QPC_VOTE, "vote", 30)])
+def test_small_circuits_every_hint_every_mode(kind, name, min_hints):
+    c = BuiltCircuit(kind, False)
+    x = th.vote_test_inputs().fill_targets() if kind == QPC_VOTE else _wormhole_inputs(kind)
+    res, stats = sweep(c, x, 0, full_every=7)
+    assert_sound(res, name, min_hints)
+    assert stats["full"] >= 1
+    flips, _ = sweep(c, x, 1, full_every=5)
+    t = assert_sound(flips, name + " (input flips)")
+    assert all(r.verdict in (0, 5) for r in flips), t                       # an input is either checked by a gate or carried by no cell at all
+
+
+def test_wormhole_circuit_every_hint():
+    """The whole leaf circuit (20 storage-proof nodes: ~3,600 is_equal inverses, ~3,800 range checks): every hint, every mode."""
+    c = BuiltCircuit(QPC_WORMHOLE, False)
+    x = _wormhole_inputs(QPC_WORMHOLE)
+    n = circuit_lib().qpc_circuit_num_hints
+    n.restype, n.argtypes = ctypes.c_size_t, [ctypes.c_void_p]
+    assert n(c.handle) > 7000
+    res, stats = sweep(c, x, 0, full_every=499)
+    t = assert_sound(res, "wormhole")
+    assert len({r.index for r in res}) == n(c.handle) and stats["full"] >= 10
+    assert t.get(("inverse", "killed"), 0) > 1000 and t.get(("base-sum limbs", "killed"), 0) + t.get(("base-sum limbs", "blocked"), 0) > 7000
+    flips, _ = sweep(c, x, 1, full_every=211)
+    assert_sound(flips, "wormhole (input flips)")
+    unused = [r.index for r in flips if r.verdict == 5]
+    assert all(r.verdict in (0, 5) for r in flips) and len(unused) < len(flips) // 2
+
+
+def _golden_node():
+    rd = lambda f: open(os.path.join(GOLD, f), "rb").read()
+    common, vb, proof = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
+    vo = vb[:len(vb) - len(common)] if vb.endswith(common) and len(vb) > len(common) else vb
+    shape = ReferenceCircuitShape(common, vo)
+    node = BuiltCircuit.aggregation(shape.desc, 1, False)
+    return node, node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [proof])
+
+
+def test_aggregation_node_every_hint_on_the_reference_golden_proof():
+    """The in-circuit verifier, on the Rust prover's own proof (bench-data/proof.bin under common.bin / verifier.bin): every hinted inverse,
+    extension inverse, 32-bit half and limb of the node that verifies it is mutated; none may survive."""
+    node, x = _golden_node()
+    w, p = node.witness(x)
+    assert check_witness(OracleCircuit(node.desc), w, p) is None
+    res, stats = sweep(node, x, 0, full_every=997)
+    t = assert_sound(res, "aggregation node over the golden proof", min_hints=500)
+    assert stats["full"] >= 5
+    kinds = {k for k, _ in t}
+    assert {"inverse", "extension inverse", "lo/hi halves", "base-sum limbs"} <= kinds, kinds
+
+
+def test_aggregation_node_rejects_every_flipped_proof_cell():
+    """Every proof-derived input cell of the node (caps, openings, query rows, Merkle siblings, final polynomial, proof-of-work witness, public
+    inputs, the verifier data) flipped AFTER generation: the matrix must violate a gate. Inputs no cell carries are listed and must be few."""
+    node, x = _golden_node()
+    flips, _ = sweep(node, x, 1, full_every=1499, modes=1)
+    assert_sound(flips, "aggregation node (input flips)", min_hints=len(x) // 2)
+    assert all(r.verdict in (0, 5) for r in flips)
+    no_cell = [r.index for r in flips if r.verdict == 5]
+    assert len(no_cell) <= len(x) // 50, "inputs that reach no gate: %r" % no_cell[:40]

@@ -1,0 +1,143 @@
+"""Host-side pools of the aggregator (CPU): thread sizing on shared boxes and multi-rank nodes, per-proof blinding keys, the bounded
+witness-buffer ring between host witness generation and device batches. Reference behaviour mirrored: independent proofs of a level are
+spread over a thread pool (wormhole/aggregator/src/circuits/tree.rs:92-103) and every proof draws its own prover randomness."""
+import importlib
+import os
+import subprocess
+import sys
+import threading
+import numpy as np
+import pytest
+from harness import BuiltCircuit, QPC_NULLIFIER, ROOT
+
+pkg = importlib.import_module("zk-circuits_amd")
+hostcpus = importlib.import_module("zk-circuits_amd.hostcpus")
+aggregator = importlib.import_module("zk-circuits_amd.aggregator")
+ffi = importlib.import_module("zk-circuits_amd.ffi")
+th = pkg.test_helpers
+
+
+def _cpu_max(tmp_path, text):
+    p = tmp_path / ("cpu.max.%s" % text.split()[0])
+    p.write_text(text)
+    return str(p)
+
+
+def test_usable_cpus_caps_affinity_by_quota_and_ranks(tmp_path, monkeypatch):
+    monkeypatch.delenv("QPGPU_HOST_THREADS", raising=False)
+    q16 = _cpu_max(tmp_path, "1600000 100000\n")                 # the driver's box: 128 CPUs visible, a 16-core share
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=q16, local_world=1) == 16
+    assert hostcpus.usable_cpus(affinity=8, cpu_max_path=q16, local_world=1) == 8
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=q16, local_world=8) == 2
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=_cpu_max(tmp_path, "max 100000\n"), local_world=8) == 16
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=_cpu_max(tmp_path, "150000 100000\n"), local_world=1) == 2   # 1.5 cores round up
+    assert hostcpus.usable_cpus(affinity=4, cpu_max_path=q16, local_world=8) == 1                                       # never 0
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=str(tmp_path / "missing"), local_world=1) == 128
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert hostcpus.usable_cpus(affinity=128, cpu_max_path=q16) == 4
+    monkeypatch.setenv("QPGPU_HOST_THREADS", "3")
+    assert hostcpus.usable_cpus() == 3
+
+
+@pytest.mark.parametrize("cores", [1, 2, 3, 8, 16, 64])
+@pytest.mark.parametrize("jobs", [1, 2, 7, 64, 512])
+def test_witness_pool_never_oversubscribes(cores, jobs):
+    outer, inner = hostcpus.witness_pool_shape(jobs, cores)
+    assert outer >= 1 and inner >= 1 and outer <= jobs
+    assert outer * inner <= max(cores, 1) or (cores == 1 and outer * inner == 1)
+    if jobs == 1:
+        assert outer == 1 and inner == min(8, cores)
+
+
+def test_sixteen_core_share_gives_at_most_sixteen_threads(tmp_path):
+    """on a box with 128 visible CPUs under a 16-core quota the pools must stay within 16 threads; with 8 ranks, within 2."""
+    q16 = _cpu_max(tmp_path, "1600000 100000\n")
+    for world, cap in ((1, 16), (8, 2)):
+        cores = hostcpus.usable_cpus(affinity=128, cpu_max_path=q16, local_world=world)
+        for jobs in (1, 8, 64, 511):
+            outer, inner = hostcpus.witness_pool_shape(jobs, cores)
+            assert outer * inner <= cap
+
+
+def test_c_side_reads_the_same_quota(tmp_path):
+    """libqpgpu.so / libqpcircuit.so size their pools from csrc/hostcpus.h: same rule (own process: the library reads the environment)."""
+    q = _cpu_max(tmp_path, "300000 100000\n")
+    code = ("import importlib,sys; sys.path.insert(0, %r); f = importlib.import_module('zk-circuits_amd.ffi'); "
+            "print(f.lib().qpgpu_usable_host_cpus())" % ROOT)
+    env = dict(os.environ, QPGPU_CGROUP_CPU_MAX=q)
+    env.pop("QPGPU_HOST_THREADS", None); env.pop("LOCAL_WORLD_SIZE", None)
+    n_aff = len(os.sched_getaffinity(0))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert int(out.strip()) == min(3, n_aff)
+    env["LOCAL_WORLD_SIZE"] = "2"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert int(out.strip()) == max(1, min(3, n_aff) // 2)
+    env["QPGPU_HOST_THREADS"] = "5"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert int(out.strip()) == 5
+
+
+def test_every_proof_of_a_batch_gets_its_own_blinding_key():
+    prod = [aggregator.proof_blinding_key(None, i) for i in range(64)]
+    assert len(set(prod)) == 64 and all(len(k) == 32 for k in prod)
+    keys = [aggregator.proof_blinding_key(5, i) for i in range(512)]
+    assert len(set(keys)) == 512
+    assert keys == [aggregator.proof_blinding_key(5, i) for i in range(512)]                    # reproducible for the tests
+    assert aggregator.proof_blinding_key(5, 1) == aggregator.proof_blinding_key(6, 0)           # a function of salt_seed + index
+    assert aggregator.proof_blinding_key(5, 1) != aggregator.proof_blinding_key(5, 1, b"node")  # leaves and nodes never share one
+
+
+def test_blinding_rows_differ_between_the_leaves_of_one_batch():
+    """two witnesses of one prove_leaves call used to share every blinding row. With per-proof keys the rows after the
+    gate rows differ in every wire column, while the gate rows of one statement stay equal."""
+    c = BuiltCircuit(QPC_NULLIFIER, True)
+    x = th.circuit_test_inputs().fill_targets(QPC_NULLIFIER)
+    w0, _ = c.witness(x, aggregator.proof_blinding_key(7, 0))
+    w1, _ = c.witness(x, aggregator.proof_blinding_key(7, 1))
+    rows = c.row_counts()
+    used = rows["rows_in_use"]
+    differ = (w0 != w1)
+    assert not differ[:, :used].any()                                   # same statement, same gate rows
+    blind = differ[:, used:]
+    assert blind.any(axis=1).all()                                      # every wire column has blinding rows of its own
+    # and a second call with the same key reproduces the witness bit for bit (what the byte-parity tests rely on)
+    w0b, _ = c.witness(x, aggregator.proof_blinding_key(7, 0))
+    assert np.array_equal(w0, w0b)
+
+
+def test_pipelined_batches_bounds_the_buffers_in_flight():
+    """Item i is generated into slot i % window and a slot is reused only after the batch that used it was proved."""
+    n, group, window = 100, 8, 24
+    lock = threading.Lock()
+    owner = [None] * window                # which item currently owns a slot
+    proved, max_live = [], [0]
+
+    def witness(i, slot):
+        with lock:
+            assert slot == i % window
+            assert owner[slot] is None, "slot %d handed to item %d while item %s still holds it" % (slot, i, owner[slot])
+            owner[slot] = i
+            max_live[0] = max(max_live[0], sum(o is not None for o in owner))
+        return (i, slot)
+
+    def prove(wit, first):
+        assert [i for i, _ in wit] == list(range(first, min(n, first + group)))
+        with lock:
+            for i, slot in wit:
+                assert owner[slot] == i
+                owner[slot] = None
+        proved.extend(i for i, _ in wit)
+        return [i * i for i, _ in wit]
+
+    out = aggregator.pipelined_batches(n, group, window, 4, witness, prove)
+    assert out == [i * i for i in range(n)] and proved == list(range(n)) and max_live[0] <= window
+
+
+def test_pipelined_batches_propagates_a_failed_witness():
+    def witness(i, slot):
+        if i == 13:
+            raise RuntimeError("Failed to prove: a child proof of this node does not verify")
+        return i
+
+    with pytest.raises(RuntimeError, match="does not verify"):
+        aggregator.pipelined_batches(40, 8, 24, 3, witness, lambda wit, first: list(wit))

@@ -11,11 +11,48 @@ on disk, so node circuits are this repo's layout, not upstream's), its witness i
 import ctypes
 import os
 import numpy as np
+import hashlib
 from . import ffi
+from .hostcpus import witness_pool_shape
 from .prover import ProofWithPublicInputs, SyntheticInputs
 
 DEFAULT_TREE_BRANCHING_FACTOR = 2   # tree.rs:17
 DEFAULT_TREE_DEPTH = 3              # tree.rs:20
+
+
+def proof_blinding_key(salt_seed, index, domain=b"leaf"):
+    """The 32-byte key of ONE proof's zk blinding rows. Production (salt_seed None): fresh OS randomness per proof, as the reference draws
+    its blinding rows from OsRng inside every prove. Tests/benches: derived from the public test key, distinct per (domain, salt_seed + index).
+    Sharing one key across the proofs of a batch would repeat the blinding rows in all of them (Builder::generate derives them from
+    (key, column) only), and the openings of many proofs would then outnumber the shared unknowns."""
+    if salt_seed is None:
+        return os.urandom(32)
+    return hashlib.sha256(ffi.TEST_SALT_KEY + b"|blinding|" + domain + b"|" + int(salt_seed + index).to_bytes(16, "little")).digest()
+
+
+def pipelined_batches(n, group, window, workers, witness, prove):
+    """Bounded producer/consumer between host witness generation and device batches: item i is generated into buffer slot i % window
+    by `witness(i, slot)` on a pool of `workers` threads, and `prove(list_of_witnesses, first_index)` takes `group` consecutive items at
+    a time; a slot is handed to a later item only after the batch that used it has been proved. Returns the concatenated results."""
+    from concurrent.futures import ThreadPoolExecutor
+    assert window >= group and window % group == 0
+    out, futures, nxt = [], {}, 0
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        def top_up(limit):
+            nonlocal nxt
+            while nxt < min(n, limit):
+                futures[nxt] = ex.submit(witness, nxt, nxt % window)
+                nxt += 1
+        top_up(window)
+        try:
+            for first in range(0, n, group):
+                wit = [futures.pop(i).result() for i in range(first, min(n, first + group))]
+                out += prove(wit, first) or []
+                top_up(first + group + window)          # the slots of the batch just proved are free again
+        finally:
+            for f in futures.values():
+                f.cancel()
+    return out
 
 
 class TreeAggregationConfig:
@@ -43,7 +80,8 @@ class WormholeProofAggregator:
         self.config = config or TreeAggregationConfig()
         self.proofs_buffer = []
         self.chunk_prover = chunk_prover
-        self._witness_pool = []         # reusable (wires, public_inputs) buffers of prove_leaves
+        self._witness_pool = []         # reusable (wires, public_inputs) buffers of prove_leaves: a ring of RING_GROUPS * GROUP
+        self._salt_streams = {}         # caller-supplied salt key -> next unused ChaCha8 stream
 
     @staticmethod
     def from_circuit_config(circuit_config, device=0):
@@ -76,31 +114,40 @@ class WormholeProofAggregator:
             raise RuntimeError("tried to add proof when proof buffer is full")
         self.proofs_buffer.append(proof)
 
+    GROUP = 16                          # leaf proofs per device batch
+    RING_GROUPS = 3                     # witness buffers kept: RING_GROUPS * GROUP (the host may run two groups ahead of the device)
+
     def prove_leaves(self, circuit_inputs_list, salt_seed=None, salt_key=None):
-        """Proves independent leaf witnesses as one stream-pipelined batch on this GPU (qpgpu_prove_batch) and pushes them.
-        Salts: ChaCha8(salt_key, stream i) for leaf i with a fresh OS-RNG key per call, unless `salt_seed` is given (tests: the
-        public test key with stream salt_seed + i, reproducible by the oracle)."""
+        """Proves independent leaf witnesses as stream-pipelined batches on this GPU (qpgpu_prove_batch) and pushes them.
+        Prover-side randomness is per PROOF, as in the reference (OsRng inside every prove): every leaf gets its own 32-byte blinding key
+        (the zk blinding rows of its witness) and its own salt stream. Salts: ChaCha8(key, stream) with a fresh OS-RNG key per call and
+        stream = leaf index; with a caller-supplied `salt_key` the stream continues from where the previous call under that aggregator
+        stopped — a (key, stream) pair must never repeat, so do not hand the same key to two aggregators. `salt_seed` (tests, benches):
+        the PUBLIC test key with stream salt_seed + i and blinding keys derived from it, reproducible by the oracle."""
         cd = self.leaf_circuit_data
         n = len(circuit_inputs_list)
-        cores = len(os.sched_getaffinity(0))
         real = n > 0 and not isinstance(circuit_inputs_list[0], SyntheticInputs)
-        outer = 1 if n <= 1 else min(n, max(2, cores // 2))                 # witnesses generated at once
-        inner = max(1, min(8, cores // outer))                              # threads inside one witness (the circuit's independent segments)
-        blinding = os.urandom(32) if salt_seed is None else ffi.TEST_SALT_KEY
+        outer, inner = witness_pool_shape(n)        # witnesses generated at once x threads inside one witness (independent segments)
         if salt_seed is not None:
             key, base = ffi.TEST_SALT_KEY, salt_seed
+        elif salt_key is not None:
+            key, base = salt_key, self._salt_streams.get(bytes(salt_key), 0)
+            self._salt_streams[bytes(salt_key)] = base + n
         else:
-            key, base = (salt_key or os.urandom(32)), 0
-        # witness matrices of built circuits are reused from call to call (a fresh 17.7 MB matrix costs more in page faults than the generation)
+            key, base = os.urandom(32), 0
+        # witness matrices of built circuits are reused (a fresh 17.7 MB matrix costs more in page faults than the generation): a ring
+        # of RING_GROUPS * GROUP buffers, released by close()
         pool = self._witness_pool
+        window = self.GROUP * self.RING_GROUPS
         if real:
             built = cd._built
-            while len(pool) < n:
+            while len(pool) < min(n, window):
                 pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
 
-        def witness(ci, slot):
+        def witness(i, slot):
+            ci = circuit_inputs_list[i]
             if not isinstance(ci, SyntheticInputs):                         # the reference's CircuitInputs on the built wormhole circuit
-                return built.witness(ci.fill_targets(built.kind), blinding, out=pool[slot], threads=inner)
+                return built.witness(ci.fill_targets(built.kind), proof_blinding_key(salt_seed, i), out=pool[slot], threads=inner)
             return cd.witness(ci.seed) if ci.wires is None else (ci.wires, ci.public_inputs)
 
         def prove(wit, first):                                             # one device batch; leaf i takes salt stream base + i
@@ -116,15 +163,16 @@ class WormholeProofAggregator:
             for i in range(b):
                 self.push_proof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs))
         if not real or n == 1:
-            prove([witness(ci, i) for i, ci in enumerate(circuit_inputs_list)], 0)
+            prove([witness(i, i) for i in range(n)], 0)
             return
         # host threads generate witnesses (the library releases the GIL) while the device proves the groups already complete
-        from concurrent.futures import ThreadPoolExecutor
-        GROUP = 16
-        with ThreadPoolExecutor(max_workers=outer) as ex:
-            futures = [ex.submit(witness, ci, i) for i, ci in enumerate(circuit_inputs_list)]
-            for first in range(0, n, GROUP):
-                prove([f.result() for f in futures[first:first + GROUP]], first)
+        pipelined_batches(n, self.GROUP, window, outer, witness, prove)
+
+    def close(self):
+        """Releases the witness buffers (and the chunk prover's circuits and buffers)."""
+        self._witness_pool = []
+        if self.chunk_prover is not None and hasattr(self.chunk_prover, "close"):
+            self.chunk_prover.close()
 
     def aggregate(self, dummy_proof=None, chunk_prover=None):
         """aggregator.rs:74-92. With a `chunk_prover` (see aggregate_to_tree) the padded leaves are aggregated to the root proof;
@@ -216,35 +264,39 @@ class RecursiveChunkProver:
             self._levels[key] = (WormholeCircuitData.from_built(node, self.device), inner, inner.constants_sigmas_cap(), list(inner.desc.circuit_digest))
         return self._levels[key]
 
-    def prove_chunks(self, chunks, level):
+    takes_first_index = True            # prove_chunks(chunks, level, first_index): see aggregate_level
+
+    def prove_chunks(self, chunks, level, first_index=0):
+        """One parent per chunk. `first_index` = position of chunks[0] among ALL chunks of this tree level (a rank of a distributed tree
+        proves a contiguous run of them): with `salt_seed` set, node i of a level takes blinding key and salt stream number first_index + i,
+        so a distributed tree reproduces the single-process tree byte for byte; without it every call draws fresh OS randomness."""
         if not chunks:
             return []
         width = len(chunks[0])
         if any(len(c) != width for c in chunks):            # a ragged last chunk gets its own (narrower) circuit, as in the reference
-            return [self.prove_chunks([c], level)[0] for c in chunks]
+            return [self.prove_chunks([c], level, first_index + i)[0] for i, c in enumerate(chunks)]
         self._level_width.setdefault(level, width)
         cd, inner, cap, digest = self.level(level, width)
         node = cd._built
 
         zk = bool(cd.desc.zero_knowledge)                 # a node takes its children's config (tree.rs:111)
-        blinding_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
+        seed = None if self.salt_seed is None else self.salt_seed + (level << 20)
 
-        # witness matrices (35 MB each at 2^15 rows) are reused from call to call: fresh ones cost more in page faults than in arithmetic
+        # witness matrices (35 MB each at 2^15 rows) are reused: a ring of RING_GROUPS * GROUP buffers per level shape
+        window = self.GROUP * self.RING_GROUPS
         pool = self._pool.setdefault((level, width), [])
-        while len(pool) < len(chunks):
+        while len(pool) < min(len(chunks), window):
             pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
+        outer, inner = witness_pool_shape(len(chunks))     # nodes generated at once x threads inside one node (its children / their FRI queries)
 
-        cores = len(os.sched_getaffinity(0))
-        outer = 1 if len(chunks) == 1 else min(len(chunks), max(2, cores // 2))           # nodes generated at once
-        inner = max(1, min(8, cores // outer))                                            # threads inside one node (its children / their FRI queries)
-
-        def witness(chunk, slot=0):
-            raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunk]
-            try:
-                return node.witness(node.aggregation_targets(cap, digest, raw), blinding_key, out=pool[slot], threads=inner)
+        def witness(i, slot=0):
+            raw = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in chunks[i]]
+            try:                                             # every node proof has its own blinding rows
+                return node.witness(node.aggregation_targets(cap, digest, raw), proof_blinding_key(seed, first_index + i, b"node") if zk else None,
+                                    out=pool[slot], threads=inner)
             except ffi.CircuitError as e:
                 raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
-        salt_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))
+        salt_key = None if not zk else (ffi.TEST_SALT_KEY if self.salt_seed is not None else os.urandom(32))   # fresh per call; stream = node index
 
         def prove(wit, first):                               # one device batch (qpgpu_prove_batch: worker streams inside the library)
             b = len(wit)
@@ -252,7 +304,7 @@ class RecursiveChunkProver:
             pp = (ffi.u64p * b)(*[p.ctypes.data_as(ffi.u64p) for _, p in wit])
             o = ffi.ProveOpts()
             if zk:                                           # proof i of the level takes salt stream base + i
-                o.salt_stream = first + ((self.salt_seed + (level << 20)) if self.salt_seed is not None else 0)
+                o.salt_stream = first + ((seed + first_index) if seed is not None else 0)
                 keep = ffi.set_salt_key(o, salt_key)         # noqa: F841
             buf = ctypes.create_string_buffer(cd.proof_size * b)
             lens = (ctypes.c_size_t * b)()
@@ -260,18 +312,13 @@ class RecursiveChunkProver:
             return [AggregatedProof(ProofWithPublicInputs(ctypes.string_at(ctypes.addressof(buf) + i * cd.proof_size, cd.proof_size), cd.num_public_inputs), cd)
                     for i in range(b)]
         if len(chunks) == 1:
-            return prove([witness(chunks[0])], 0)
+            return prove([witness(0)], 0)
         # witnesses on host threads (generation releases the GIL), proofs in device batches of GROUP nodes: the device proves a group while
         # the host generates the next ones
-        from concurrent.futures import ThreadPoolExecutor
-        out = []
-        with ThreadPoolExecutor(max_workers=outer) as ex:
-            futures = [ex.submit(witness, c, i) for i, c in enumerate(chunks)]
-            for first in range(0, len(chunks), self.GROUP):
-                out += prove([f.result() for f in futures[first:first + self.GROUP]], first)
-        return out
+        return pipelined_batches(len(chunks), self.GROUP, window, outer, witness, prove)
 
-    GROUP = 8
+    GROUP = 8                           # node proofs per device batch
+    RING_GROUPS = 3                     # witness buffers kept per level shape: RING_GROUPS * GROUP
 
     def __call__(self, chunk, level):
         return self.prove_chunks([chunk], level)[0]
@@ -287,14 +334,21 @@ class RecursiveChunkProver:
         return self.leaf.proof_size if level == 0 else self.level(level - 1, width)[0].proof_size
 
 
-def aggregate_level(proofs, chunk_prover, config, level):
-    """tree.rs:92-103: consecutive chunks of `tree_branching_factor` children, one parent each, order preserved. `chunk_prover(chunk,
-    level)` returns an AggregatedProof; the reference maps it with par_chunks — a prover may batch its chunks on the device instead."""
-    b = config.tree_branching_factor
-    chunks = [proofs[i:i + b] for i in range(0, len(proofs), b)]
+def _prove_chunks(chunk_prover, chunks, level, first_index):
     if hasattr(chunk_prover, "prove_chunks"):                     # a device prover takes the whole level as one batch (par_chunks analogue)
+        if getattr(chunk_prover, "takes_first_index", False):
+            return chunk_prover.prove_chunks(chunks, level, first_index)
         return chunk_prover.prove_chunks(chunks, level)
     return [chunk_prover(c, level) for c in chunks]
+
+
+def aggregate_level(proofs, chunk_prover, config, level, first_index=0):
+    """tree.rs:92-103: consecutive chunks of `tree_branching_factor` children, one parent each, order preserved. `chunk_prover(chunk,
+    level)` returns an AggregatedProof; the reference maps it with par_chunks — a prover may batch its chunks on the device instead.
+    `first_index`: position of the first chunk among all chunks of the level (non-zero on ranks > 0 of a distributed tree)."""
+    b = config.tree_branching_factor
+    chunks = [proofs[i:i + b] for i in range(0, len(proofs), b)]
+    return _prove_chunks(chunk_prover, chunks, level, first_index)
 
 
 def aggregate_to_tree(leaf_proofs, config, chunk_prover):
@@ -311,7 +365,7 @@ def aggregate_to_tree(leaf_proofs, config, chunk_prover):
 def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof_size_of_level, group=None, device=None):
     """The same tree over torch.distributed ranks: rank r holds a contiguous, equally sized run of the leaves.
     While a rank's run holds whole chunks, a level is local work with no communication. Once it does not, the level's proofs
-    (fixed-size blobs) are all-gathered in rank order and the chunks are dealt out to ranks 0..chunks-1; every rank returns the root.
+    (fixed-size blobs) are all-gathered in rank order and the chunks are dealt out in contiguous runs to the first ranks; every rank returns the root.
     `proof_size_of_level(level)` is the byte size of the proofs that ENTER that level (level 0: leaf proofs). One collective per
     level at the top of the tree, none below: RCCL (backend "nccl") on GPU tensors, gloo on CPU tensors."""
     import torch.distributed as dist
@@ -321,7 +375,7 @@ def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof
     total = len(proofs) * world
     while total > 1:
         if spread and len(proofs) % b == 0 and len(proofs) >= b:
-            proofs = [p.proof for p in aggregate_level(proofs, chunk_prover, config, level)]
+            proofs = [p.proof for p in aggregate_level(proofs, chunk_prover, config, level, first_index=rank * (len(proofs) // b))]
         else:
             if spread:
                 everything = gather_proofs(proofs, proof_size_of_level(level), group=group, device=device)
@@ -329,17 +383,15 @@ def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof
             else:
                 everything = proofs                                     # already replicated on every rank
             chunks = [everything[i:i + b] for i in range(0, len(everything), b)]
-            my_chunks = [c for i, c in enumerate(chunks) if i % world == rank]
-            if hasattr(chunk_prover, "prove_chunks") and my_chunks:      # a device prover batches this rank's chunks of the level
-                mine = [p.proof for p in chunk_prover.prove_chunks(my_chunks, level)]
-            else:
-                mine = [chunk_prover(c, level).proof for c in my_chunks]
-            # one parent per chunk; parents are gathered back in chunk order (rank i % world proved chunk i)
+            # rank r proves the contiguous run [r * per_rank, (r + 1) * per_rank) of the level's chunks: ranks 0 .. ceil(chunks / per_rank) - 1 work
             per_rank = (len(chunks) + world - 1) // world
+            my_chunks = chunks[rank * per_rank:(rank + 1) * per_rank]
+            mine = [p.proof for p in _prove_chunks(chunk_prover, my_chunks, level, rank * per_rank)] if my_chunks else []
+            # one parent per chunk; the gather returns them in rank order = chunk order (padding blobs of idle ranks fall behind the last chunk)
             size = proof_size_of_level(level + 1)
             padded = mine + [bytes(size)] * (per_rank - len(mine))
             gathered = gather_proofs(padded, size, group=group, device=device)
-            proofs = [gathered[(i % world) * per_rank + i // world] for i in range(len(chunks))]
+            proofs = gathered[:len(chunks)]
         total = (total + b - 1) // b
         level += 1
     if spread:                                                          # a single rank with a single leaf run

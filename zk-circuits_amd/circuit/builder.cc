@@ -169,7 +169,7 @@ void Builder::build() {
   { const int ncol = nsel + 2 + R;                               // one digest per column (independent sponges, spread over host threads), then one over them
     std::vector<u64> col_digest((size_t)4 * ncol);
     auto hash_cols = [&](int lo, int hi) { for (int col = lo; col < hi; col++) hash_no_pad(cs + (size_t)col * n_, n_, &col_digest[4 * (size_t)col]); };
-    const int nthr = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const int nthr = std::max(1, std::min(8, qp::usable_cpus()));
     std::vector<std::thread> pool;
     for (int t = 1; t < nthr; t++) pool.emplace_back(hash_cols, ncol * t / nthr, ncol * (t + 1) / nthr);
     hash_cols(0, ncol / nthr);

@@ -15,6 +15,7 @@
 #include "../../include/qpgpu.h"
 #include "../csrc/poseidon.h"
 #include "../csrc/salt.h"
+#include "../csrc/hostcpus.h"
 #include <map>
 #include <string>
 #include <tuple>
@@ -220,6 +221,14 @@ class Builder {
   // (32 bytes) seeds the zk blinding rows. Returns "" or the failure.
   std::string generate(const u64* inputs, const uint8_t* blinding_key, u64* wires, u64* public_inputs, int threads = 1) const;
   bool parallel_replay() const { return parallel_ok_; }
+
+  // ---- soundness testing (mutation.cc): hint operations = the values a generator supplies instead of a gate computing them
+  // (OP_INV, OP_LOHI, OP_EXTINV, the limbs of OP_SPLIT), numbered in program order.
+  struct MutationResult { uint32_t index, kind, mode, verdict; u64 conflicts, changed_classes, rows; };
+  typedef int (*WitnessCheck)(void* ctx, const u64* wires, const u64* public_inputs, const uint32_t* rows, size_t num_rows, int full);
+  size_t num_hints() const;
+  std::string mutation_sweep(const u64* inputs, const uint8_t* blinding_key, uint32_t what, size_t first, size_t step, size_t max_count,
+                             uint32_t modes_mask, u64 seed, uint32_t full_every, WitnessCheck check, void* ctx, std::vector<MutationResult>& out) const;
 
  private:
   enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON, OP_EXTINV, OP_LOHI };

@@ -249,7 +249,7 @@ void qpc_circuit_row_counts(const qpc_circuit* c, uint32_t out[7]) { if (!c || !
 int qpc_generate_witness_mt(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint64_t* wires, uint64_t* public_inputs, uint32_t threads) { return guard([&]() -> int {
   if (!c || !inputs || !wires || (!public_inputs && c->b.desc().num_public_inputs)) return fail(QPGPU_ERR_ARG, "null argument");
   if (num_inputs != c->b.num_inputs()) return fail(QPGPU_ERR_ARG, "expected " + std::to_string(c->b.num_inputs()) + " input values, got " + std::to_string(num_inputs));
-  if (threads == 0) threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  if (threads == 0) threads = (uint32_t)std::max(1, std::min(8, qp::usable_cpus()));
   const std::string e = c->b.generate(inputs, blinding_key, wires, public_inputs, (int)threads);
   if (!e.empty()) return fail(QPGPU_ERR_WITNESS, e);
   return 0;
@@ -393,4 +393,19 @@ extern "C" int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, u
   *num_outputs = n_out;
   b.build();
   *out = c.release(); return 0;
+}); }
+
+extern "C" size_t qpc_circuit_num_hints(const qpc_circuit* c) { return c ? c->b.num_hints() : 0; }
+extern "C" int qpc_mutation_sweep(const qpc_circuit* c, const uint64_t* inputs, size_t num_inputs, const uint8_t* blinding_key, uint32_t what, size_t first, size_t step,
+                                  uint32_t modes_mask, uint64_t seed, uint32_t full_every, qpc_witness_check_fn check, void* ctx, qpc_mutation_result* out, size_t cap,
+                                  size_t* count) { return guard([&]() -> int {
+  if (!c || !inputs || !check || !out || !count) return fail(QPGPU_ERR_ARG, "null argument");
+  if (num_inputs != c->b.num_inputs()) return fail(QPGPU_ERR_ARG, "expected " + std::to_string(c->b.num_inputs()) + " input values, got " + std::to_string(num_inputs));
+  static_assert(sizeof(qpc_mutation_result) == sizeof(Builder::MutationResult), "same layout");
+  std::vector<Builder::MutationResult> res;
+  const std::string e = c->b.mutation_sweep(inputs, blinding_key, what, first, step, cap, modes_mask, seed, full_every, (Builder::WitnessCheck)check, ctx, res);
+  *count = std::min(res.size(), cap);
+  memcpy(out, res.data(), *count * sizeof(qpc_mutation_result));
+  if (!e.empty()) return fail(QPGPU_ERR_WITNESS, e);
+  return 0;
 }); }

@@ -9,6 +9,7 @@
 #include "../../include/qpgpu_internal.h"
 #include "kernels.h"
 #include "options.h"
+#include "hostcpus.h"
 #include "salt.h"
 #include "poseidon.h"
 #include "proof_format.h"
@@ -30,10 +31,13 @@ thread_local std::string g_last_error;
 int set_err(int code, const std::string& m) { g_last_error = m; return code; }
 
 // ---- options (options.h): the one place that reads the environment
-// Two buffers and an index: a refresh fills the inactive one and then flips, so readers racing with qpgpu_ctx_create see either the old
-// or the new set, never a half-written one.
-static Options g_opts[2]; static std::atomic<int> g_opts_cur(0); static std::mutex g_opts_mu;
-const Options& opts() { return g_opts[g_opts_cur.load(std::memory_order_acquire)]; }
+// A set of options is immutable once published: a refresh that finds the environment unchanged keeps the current set, one that finds a
+// change publishes a NEW set and leaves the old one alive (a few hundred bytes per deliberate change of the environment), so a proof
+// that is running while another thread creates a context never sees a buffer being rewritten under it, and — unless the host changes
+// the variables on purpose — never sees a knob change mid-proof either.
+static std::atomic<const Options*> g_opts_cur{nullptr}; static std::mutex g_opts_mu;
+static const Options g_opts_default{};
+const Options& opts() { const Options* p = g_opts_cur.load(std::memory_order_acquire); return p ? *p : g_opts_default; }
 void options_refresh_from_env() {
   std::lock_guard<std::mutex> lk(g_opts_mu);
   Options o;
@@ -51,12 +55,14 @@ void options_refresh_from_env() {
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
   o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift); o.poseidon_fast = geti("QPGPU_POSEIDON_FAST", o.poseidon_fast);
   o.verify_coop_max = geti("QPGPU_VERIFY_COOP_MAX", o.verify_coop_max);
-  const int nxt = 1 - g_opts_cur.load(std::memory_order_relaxed);
-  g_opts[nxt] = o; g_opts_cur.store(nxt, std::memory_order_release);
+  const Options* cur = g_opts_cur.load(std::memory_order_relaxed);
+  if (cur && memcmp(cur, &o, sizeof o) == 0) return;                 // all-int struct, no padding: bytewise equality is value equality
+  g_opts_cur.store(new Options(o), std::memory_order_release);       // never freed: readers may still hold the previous set
 }
-// At library load: ask the runtime for 8 hardware queues unless the host has chosen (only effective if HIP is not initialised yet in this
-  // process — a host that initialises HIP first, e.g. through PyTorch, sets GPU_MAX_HW_QUEUES itself: bench.py does).
-namespace { struct OptionsInit { OptionsInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); options_refresh_from_env(); } } g_options_init; }
+static_assert(sizeof(Options) % sizeof(int) == 0, "Options is plain ints");
+// The library never touches the host's environment. Eight worker streams need eight hardware queues: the HOST exports GPU_MAX_HW_QUEUES=8
+// before HIP initialises if it wants them (zk-circuits_amd/ffi.py and bench.py do), otherwise four workers run.
+namespace { struct OptionsInit { OptionsInit() { options_refresh_from_env(); } } g_options_init; }
 }
 using namespace qp;
 
@@ -209,21 +215,10 @@ static void ws_destroy(Workspace* w) {
   delete w;
 }
 
-// Host cores this process may use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of its cores).
-static int usable_cpus() {
-  static const int n = [] {
-    int k = (int)std::thread::hardware_concurrency();
-    cpu_set_t set; CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) k = a; }
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-      char q[64]; long long per = 0;
-      if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long long c = atoll(q) / per; if (c >= 1 && c < k) k = (int)c; }
-      fclose(f);
-    }
-    return k > 0 ? k : 1;
-  }();
-  return n;
-}
+using qp::usable_cpus;          // csrc/hostcpus.h: affinity mask, capped by the cgroup CPU quota, divided by the ranks of this node
+static std::atomic<uint64_t> g_handoff_fallbacks{0};
+extern "C" int qpgpu_usable_host_cpus(void) { return qp::usable_cpus_uncached(); }
+extern "C" uint64_t qpgpu_handoff_fallbacks(void) { return g_handoff_fallbacks.load(std::memory_order_relaxed); }
 
 // Brings `words` u64 from device memory to w->pinned and waits for them. Fast path: publish kernel + spin on the mapped flag;
 // fallback (no mapped pointer, or the flag does not arrive): copy + stream synchronise, which also surfaces kernel faults.
@@ -253,7 +248,7 @@ static int fetch_to_host(Workspace* w, hipStream_t s, const u64* src, size_t wor
         if ((++naps & 0x3F) == 0) {                  // every ~few ms: has the stream died?
           hipError_t q = hipStreamQuery(s);
           if (q != hipSuccess && q != hipErrorNotReady) return set_err(QPGPU_ERR_HIP, std::string("stream error while waiting: ") + hipGetErrorString(q));
-          if (q == hipSuccess && *flag != seq && naps > 4096) break;   // kernel finished but the flag never arrived: fall back
+          if (q == hipSuccess && *flag != seq && naps > 4096) { g_handoff_fallbacks.fetch_add(1, std::memory_order_relaxed); break; }   // kernel finished but the flag never arrived: fall back (counted)
         }
       }
     }
@@ -868,7 +863,10 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
   Workspace* w = nullptr; int rc = ws_acquire(c, &w); if (rc) return rc;
   hipStream_t s = (opts && opts->stream) ? (hipStream_t)opts->stream : w->stream;
   rc = prove_one(c, w, s, wires, public_inputs, opts, salt_source(opts, 0, c->N), out);
-  if (rc != 0) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(w->side); w->pev_used = 0; }      // nothing of this proof may still run when the workspace is recycled
+  if (rc != 0) {                              // nothing of this proof may still run when the workspace is recycled, and no byte derived from
+    (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(w->side); w->pev_used = 0;      // a refused witness may stay in the caller's buffer
+    memset(out, 0, c->lay.total);
+  }
   ws_release(c, w);
   if (rc == 0 && out_len) *out_len = c->lay.total;
   return rc;
@@ -908,7 +906,10 @@ int qpgpu_prove_batch(qpgpu_circuit* c, size_t batch, const uint64_t* const* wir
   for (int t = 1; t < workers; t++) { try { th.emplace_back(body); } catch (...) { break; } }     // fewer workers if threads cannot be created
   body();
   for (auto& t : th) t.join();
-  if (first_rc.load()) return set_err(first_rc.load(), emsg);
+  if (first_rc.load()) {                       // a failed batch releases nothing: every slot is cleared, also those of proofs that had completed
+    for (size_t i = 0; i < batch; i++) { memset(out + i * out_stride, 0, c->lay.total); if (out_lens) out_lens[i] = 0; }
+    return set_err(first_rc.load(), emsg);
+  }
   return 0;
 }); }
 

@@ -15,6 +15,7 @@
 #include "../../include/qpgpu_internal.h"
 #include "kernels.h"
 #include "options.h"
+#include "hostcpus.h"
 #include "proof_format.h"
 #include <string>
 #include <vector>
@@ -509,7 +510,7 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
         } catch (...) { work[i].reason = "internal error while parsing"; }
       }
     };
-    size_t nthreads = std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
+    size_t nthreads = (size_t)qp::usable_cpus(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
     std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
     body(); for (auto& t : th) t.join();
   }
@@ -566,7 +567,7 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
           }
         }
       };
-      size_t nthreads = std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
+      size_t nthreads = (size_t)qp::usable_cpus(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
       std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
       body(); for (auto& t : th) t.join(); }
     const size_t bytes = words * 8 + ok_words * 4 + 64;

@@ -88,6 +88,9 @@ def lib():
         if not os.path.exists(so):
             raise ImportError("zk-circuits_amd: %s not built — run `python -c \"import __graft_entry__ as g; g.build()\"` "
                               "(hipcc --offload-arch=gfx950)" % so)
+        # the host's choice, made before the HIP runtime initialises: eight hardware queues, so that qpgpu_prove_batch's eight worker
+        # streams overlap (ROCm's default of four serialises them; the library itself never touches the environment)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = ctypes.CDLL(so)
         # ---- include/qpgpu.h
         L.qpgpu_last_error.restype = ctypes.c_char_p
@@ -124,6 +127,7 @@ def lib():
         L.qpgpu_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.qpgpu_profile_name.restype = ctypes.c_char_p
         L.qpgpu_last_stage_ms.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        L.qpgpu_handoff_fallbacks.restype = ctypes.c_uint64
         L.qpgpu_test_permute.argtypes = [u64p, ctypes.c_size_t]
         L.qpgpu_test_permute_form.argtypes = [u64p, ctypes.c_size_t, ctypes.c_int]
         L.qpgpu_test_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
