@@ -121,13 +121,14 @@ def test_wormhole_circuit_every_hint():
     assert all(r.verdict in (0, 5) for r in flips) and len(unused) < len(flips) // 2
 
 
-def _golden_node():
+def _golden_node(with_shape=False):
     rd = lambda f: open(os.path.join(GOLD, f), "rb").read()
     common, vb, proof = rd("common.bin"), rd("verifier.bin"), rd("proof.bin")
     vo = vb[:len(vb) - len(common)] if vb.endswith(common) and len(vb) > len(common) else vb
     shape = ReferenceCircuitShape(common, vo)
     node = BuiltCircuit.aggregation(shape.desc, 1, False)
-    return node, node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [proof])
+    x = node.aggregation_targets(shape.constants_sigmas_cap, shape.desc.circuit_digest, [proof])
+    return (node, x, shape, proof) if with_shape else (node, x)
 
 
 def test_aggregation_node_every_hint_on_the_reference_golden_proof():
@@ -144,11 +145,38 @@ def test_aggregation_node_every_hint_on_the_reference_golden_proof():
 
 
 def test_aggregation_node_rejects_every_flipped_proof_cell():
-    """Every proof-derived input cell of the node (caps, openings, query rows, Merkle siblings, final polynomial, proof-of-work witness, public
-    inputs, the verifier data) flipped AFTER generation: the matrix must violate a gate. Inputs no cell carries are listed and must be few."""
-    node, x = _golden_node()
+    """Every input cell of the node (the child's caps, openings, query rows, Merkle siblings, final polynomial, proof-of-work witness and public
+    inputs, and the verifier data) flipped AFTER generation: the matrix must violate a gate. The one exception is by design: the verifier
+    data's constants/sigmas cap is a private input of the node (tree.rs:113-114) that nothing hashes, so a cap entry that none of this
+    proof's 28 queries lands under multiplies a zero indicator and is free; every entry a query does select is pinned."""
+    from harness import replay_transcript
+    node, x, shape, proof = _golden_node(with_shape=True)
     flips, _ = sweep(node, x, 1, full_every=1499, modes=1)
-    assert_sound(flips, "aggregation node (input flips)", min_hints=len(x) // 2)
-    assert all(r.verdict in (0, 5) for r in flips)
-    no_cell = [r.index for r in flips if r.verdict == 5]
+    d = shape.desc
+    selected = {q >> (d.degree_bits + d.fri_rate_bits - d.fri_cap_height) for q in replay_transcript(d, proof)["query_indices"]}
+    free_cap = {4 * j + e for j in range(1 << d.fri_cap_height) if j not in selected for e in range(4)}       # the cap comes first among the inputs
+    assert 0 < len(free_cap) < 4 * 8
+    survivors = {r.index for r in flips if r.verdict == 2}
+    assert survivors == free_cap, (sorted(survivors), sorted(free_cap))
+    rest = [r for r in flips if r.index not in free_cap]
+    assert_sound(rest, "aggregation node (input flips)", min_hints=len(x) // 2)
+    assert all(r.verdict in (0, 5) for r in rest)
+    no_cell = [r.index for r in rest if r.verdict == 5]
     assert len(no_cell) <= len(x) // 50, "inputs that reach no gate: %r" % no_cell[:40]
+
+
+def test_the_sweep_finds_planted_under_constrained_hints():
+    """Negative control: the builder-fuzz programs (qpc_test_random_circuit) contain, on purpose, an extension inverse nothing constrains and a
+    32-bit decomposition without the canonical-form check. The sweep must report survivors there — an unpinned extension inverse, and the
+    non-canonical (x + p) pair of a lo/hi split — while the constrained hints of the same programs (is_equal, inverse * x = 1, limbs) die."""
+    seen = collections.Counter()
+    for seed in range(8):
+        c, inputs, _expected = BuiltCircuit.random_program(seed, zero_knowledge=False, num_inputs=8 + seed, num_ops=150 + 40 * seed)
+        res, _ = sweep(c, inputs, 0, full_every=13)
+        for r in res:
+            seen[(KINDS.get(r.kind), r.mode, VERDICTS[r.verdict])] += 1
+        assert not [r for r in res if r.verdict == 3]
+        assert not [r for r in res if r.kind == 3 and r.verdict in (1, 2)]                     # limbs: always pinned by the BaseSum row
+    assert sum(v for (k, m, vd), v in seen.items() if k == "extension inverse" and vd in ("SURVIVED", "benign")) > 0, seen
+    assert seen[("lo/hi halves", 3, "SURVIVED")] > 0, seen                                      # missing canonicity check found
+    assert not [k for k in seen if k[0] == "lo/hi halves" and k[1] in (0, 1, 4) and k[2] == "SURVIVED"], seen   # sum and ranges are pinned
