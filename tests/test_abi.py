@@ -30,7 +30,7 @@ def test_circuit_library_exports_exactly_its_header():
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
     exported = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and not l.split()[2].startswith("_Z")}
     declared = set(declared_symbols("qpcircuit.h")) | set(declared_symbols("qpcircuit_internal.h"))
-    assert set(declared_symbols("qpcircuit_internal.h")) - set(declared_symbols("qpcircuit.h")) == {"qpc_test_random_circuit"}
+    assert set(declared_symbols("qpcircuit_internal.h")) - set(declared_symbols("qpcircuit.h")) == {"qpc_test_random_circuit", "qpc_circuit_num_hints", "qpc_mutation_sweep"}     # the fuzz hook and the hint-soundness sweep
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     assert {"qpc_circuit_build", "qpc_generate_witness", "qpw_fill_targets", "qpv_fill_targets"} <= declared
     ldd = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
@@ -46,7 +46,7 @@ def test_library_exports_nothing_undeclared():
     declared = set(declared_symbols("qpgpu.h")) | set(declared_symbols("qpgpu_internal.h"))
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     internal = set(declared_symbols("qpgpu_internal.h")) - set(declared_symbols("qpgpu.h"))
-    assert all(s.startswith(("qpgpu_test_", "qpgpu_bench_", "qpgpu_profile_", "qpgpu_replay_", "qpgpu_last_stage")) for s in internal), sorted(internal)
+    assert all(s.startswith(("qpgpu_test_", "qpgpu_bench_", "qpgpu_profile_", "qpgpu_replay_", "qpgpu_last_stage", "qpgpu_handoff_fallbacks", "qpgpu_usable_host_cpus")) for s in internal), sorted(internal)
 
 
 def test_product_library_does_not_link_the_oracle():
