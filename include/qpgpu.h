@@ -153,6 +153,33 @@ size_t qpgpu_verifier_proof_size(const qpgpu_verifier* v);
  * Returns 0 if every proof was accepted, QPGPU_ERR_VERIFY if any was rejected, another negative status if the batch could not run. */
 int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_stride, size_t proof_len, size_t count, int32_t* results);
 
+/* Page-locked host memory for witness matrices. qpgpu_prove / qpgpu_prove_batch take the wire matrix from any host memory; from pageable
+ * memory the runtime stages the 17.7 MB (leaf) / 35 MB (tree node) through its own bounce buffers on the calling thread, from memory
+ * obtained here the copy is one DMA transfer that overlaps the other streams' kernels (the reference keeps its witness in a Vec: this is
+ * the allocation a host that generates witnesses into a reusable buffer should use instead). Free with qpgpu_host_free. */
+int qpgpu_host_alloc(size_t bytes, void** out);
+void qpgpu_host_free(void* p);
+
+/* ---- The exchange of the sharded path: independent proofs are proved one-per-GPU with no data-path collective; what
+ * precedes the aggregator step is an all-gather of the fixed-size proof blobs over RCCL / xGMI (the reference hands proofs between rayon
+ * workers in shared memory, wormhole/aggregator/src/circuits/tree.rs:92-103). One communicator per rank (= per GPU, per process):
+ *   rank 0 calls qpgpu_comm_unique_id and hands the 128 bytes to every rank out of band (a file, a socket, the launcher's store);
+ *   every rank calls qpgpu_comm_create(ctx of its GPU, rank, world, id) — collective: it returns when all ranks have joined;
+ *   qpgpu_gather_proofs: every rank passes `count` blobs of `proof_size` bytes (the same on every rank) and receives all of them in
+ *   rank order, out[(r * count + i) * proof_size]. Host pointers in and out; the call blocks until the data has arrived.
+ * librccl is opened at run time next to the HIP runtime this library uses (QPGPU_RCCL_LIB overrides the path); without it these
+ * calls return QPGPU_ERR_NO_DEVICE and everything else works. A communicator serialises its calls; use one per thread that gathers. */
+#define QPGPU_COMM_ID_BYTES 128
+typedef struct qpgpu_comm qpgpu_comm;
+int qpgpu_comm_unique_id(uint8_t id[QPGPU_COMM_ID_BYTES]);
+int qpgpu_comm_create(qpgpu_ctx* ctx, int rank, int world, const uint8_t id[QPGPU_COMM_ID_BYTES], qpgpu_comm** out);
+void qpgpu_comm_destroy(qpgpu_comm* comm);
+int qpgpu_comm_rank(const qpgpu_comm* comm);
+int qpgpu_comm_world(const qpgpu_comm* comm);
+int qpgpu_gather_proofs(qpgpu_comm* comm, const uint8_t* local, size_t count, size_t proof_size, uint8_t* out);
+/* Version code of the RCCL library in use (ncclGetVersion), 0 if none could be opened. */
+int qpgpu_comm_rccl_version(void);
+
 #ifdef __cplusplus
 }
 #endif

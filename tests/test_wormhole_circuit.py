@@ -332,6 +332,35 @@ def test_builder_fuzz_random_programs(seed):
         pass
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_builder_fuzz_with_the_recursion_gates(seed):
+    """The same fuzz with the recursive verifier's gates mixed in (ArithmeticExtension, Reducing, ReducingExtension, RandomAccess, PoseidonMds,
+    CosetInterpolation, Exponentiation — layouts of SURVEY.md App. D as the oracle and the device evaluate them): every natively computed
+    value is reproduced (Horner reductions over one to three rows, list look-ups, a native Lagrange interpolation, native powers), the
+    witness satisfies every gate and copy constraint of a gate list with four selector groups, and the oracle proves and verifies it."""
+    c, inputs, expected = BuiltCircuit.random_program(100 + seed, zero_knowledge=(seed == 1), num_inputs=8 + seed, num_ops=150 + 40 * seed, recursion_gates=True)
+    assert c.desc.num_gates == 13 and c.desc.num_selector_groups == 4 and c.desc.num_constants == 6
+    tags = [c.desc.gates[i].tag for i in range(c.desc.num_gates)]
+    assert tags == [9, 3, 12, 10, 2, 15, 14, 0, 1, 5, 13, 4, 11]                # by degree: Noop | Constant PublicInput PoseidonMds | BaseSum Reducing ReducingExt | Arithmetic ArithmeticExt | Exp | RandomAccess | Coset | Poseidon
+    w, p = c.witness(inputs, bytes(range(32)))
+    assert list(p) == list(expected)
+    oc = OracleCircuit(c.desc)
+    assert check_witness(oc, w, p) is None
+    if seed in (0, 1):
+        assert oc.verify(oc.prove(w, p, salts=_salts_for(c) if c.desc.zero_knowledge else None)) is None
+    bad = inputs.copy(); bad[0] = (int(bad[0]) + 1) % P
+    try:
+        _, p2 = c.witness(bad, bytes(range(32)))
+        assert list(p2) != list(expected)
+    except CircuitError:
+        pass
+
+
+def _salts_for(c):
+    from harness import keyed_salts, TEST_SALT_KEY
+    return keyed_salts(TEST_SALT_KEY, 3, c.N)
+
+
 def test_built_wormhole_circuit_has_the_reference_common_circuit_data(circuits):
     """The CommonCircuitData of the wormhole circuit built here under standard_recursion_zk_config, written in plonky2's byte format by the
     product's writer, is byte-identical to the reference's wormhole/bench-data/common.bin (1,045 bytes): circuit config, FRI parameters and

@@ -141,8 +141,8 @@ class WormholeProofAggregator:
         window = self.GROUP * self.RING_GROUPS
         if real:
             built = cd._built
-            while len(pool) < min(n, window):
-                pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
+            while len(pool) < min(n, window):                                # page-locked: the device pulls a witness with one DMA transfer
+                pool.append(ffi.witness_buffer(cd.num_wires, cd.n, cd.num_public_inputs))
 
         def witness(i, slot):
             ci = circuit_inputs_list[i]
@@ -170,6 +170,8 @@ class WormholeProofAggregator:
 
     def close(self):
         """Releases the witness buffers (and the chunk prover's circuits and buffers)."""
+        for buf in self._witness_pool:
+            ffi.release_witness_buffer(buf)
         self._witness_pool = []
         if self.chunk_prover is not None and hasattr(self.chunk_prover, "close"):
             self.chunk_prover.close()
@@ -199,13 +201,59 @@ class WormholeProofAggregator:
         return AggregatedLeaves(proofs, num_real)
 
 
+_native_comms = {}          # (process group id, device index) -> ffi.ProofComm, or False when the native path is not to be used
+
+
+def native_comm(group=None, device=None):
+    """The native RCCL communicator (include/qpgpu.h qpgpu_comm_*) matching a torch.distributed process group whose backend is RCCL:
+    rank 0 draws the unique id, torch.distributed carries the 128 bytes to the other ranks, every rank joins. Created once per group and
+    cached; None when the group is not on RCCL, when QPGPU_NATIVE_GATHER=0, or when a rank could not create its communicator (the
+    decision is agreed between the ranks, so that either all of them take the native path or none)."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("QPGPU_NATIVE_GATHER", "1") == "0" or dist.get_backend(group) != "nccl" or device is None:
+        return None
+    dev = torch.device(device)
+    key = (id(group) if group is not None else 0, dev.index or 0)
+    if key not in _native_comms:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ok, uid = 1, bytes(ffi.COMM_ID_BYTES)
+        if rank == 0:
+            try:
+                uid = ffi.ProofComm.unique_id()
+            except Exception:
+                ok = 0
+        t = torch.tensor(list(uid) + [ok], dtype=torch.uint8, device=dev)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        raw = bytes(t.cpu().tolist())
+        comm = None
+        if raw[-1] == 1:
+            try:
+                comm = ffi.ProofComm(rank, world, raw[:-1], dev.index or 0)
+            except Exception:
+                comm = None
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            if comm is not None:
+                comm.close()
+            comm = None
+        _native_comms[key] = comm if comm is not None else False
+    return _native_comms[key] or None
+
+
 def gather_proofs(local_proofs, proof_size, group=None, device=None):
-    """All ranks contribute their fixed-size proof blobs; every rank gets the concatenation in rank order.
-    torch.distributed all_gather over RCCL (backend "nccl") on GPU tensors, gloo on CPU tensors."""
+    """All ranks contribute their fixed-size proof blobs; every rank gets the concatenation in rank order. On an RCCL group the exchange
+    is the library's own qpgpu_gather_proofs (ncclAllGather behind the C-ABI, what a Rust host calls); torch.distributed's all_gather
+    serves gloo groups (CPU tensors: the tests) and is the path taken if the native communicator could not be set up."""
     import torch
     import torch.distributed as dist
     k = len(local_proofs)
     local_proofs = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in local_proofs]
+    comm = native_comm(group, device)
+    if comm is not None:
+        return comm.gather(local_proofs, proof_size)
     flat = np.frombuffer(b"".join(local_proofs), dtype=np.uint8).copy() if k else np.zeros(0, dtype=np.uint8)
     t = torch.from_numpy(flat)
     if device is not None:
@@ -253,7 +301,7 @@ class RecursiveChunkProver:
         self.node_zero_knowledge = node_zero_knowledge
         self._levels = {}               # (level, children per node) -> (WormholeCircuitData of the node circuit, inner circuit data, its cap, its digest)
         self._level_width = {}          # level -> children per node of the (full) chunks proved at that level
-        self._pool = {}                 # (level, children per node) -> reusable (wires, public_inputs) buffers
+        self._pool = {}                 # (wires, rows) of a node circuit -> ring of reusable page-locked witness matrices
 
     def level(self, level, width):
         from .prover import WormholeCircuitData
@@ -282,11 +330,13 @@ class RecursiveChunkProver:
         zk = bool(cd.desc.zero_knowledge)                 # a node takes its children's config (tree.rs:111)
         seed = None if self.salt_seed is None else self.salt_seed + (level << 20)
 
-        # witness matrices (35 MB each at 2^15 rows) are reused: a ring of RING_GROUPS * GROUP buffers per level shape
+        # witness matrices (35 MB each at 2^15 rows) are reused: ONE ring of RING_GROUPS * GROUP page-locked matrices per matrix shape
+        # (every level of a tree has the same), with each level's own public-input vectors beside it
         window = self.GROUP * self.RING_GROUPS
-        pool = self._pool.setdefault((level, width), [])
-        while len(pool) < min(len(chunks), window):
-            pool.append((np.empty((cd.num_wires, cd.n), dtype=np.uint64), np.zeros(cd.num_public_inputs, dtype=np.uint64)))
+        mats = self._pool.setdefault((cd.num_wires, cd.n), [])
+        while len(mats) < min(len(chunks), window):
+            mats.append(ffi.witness_buffer(cd.num_wires, cd.n, 0))
+        pool = [(mats[i][0], np.zeros(cd.num_public_inputs, dtype=np.uint64)) for i in range(min(len(chunks), window))]
         outer, inner = witness_pool_shape(len(chunks))     # nodes generated at once x threads inside one node (its children / their FRI queries)
 
         def witness(i, slot=0):
@@ -327,6 +377,9 @@ class RecursiveChunkProver:
         """Frees the node circuits' device memory and the witness buffers (proofs already returned stay valid; their circuit_data does not)."""
         for cd, _, _, _ in self._levels.values():
             cd.close()
+        for ring in self._pool.values():
+            for buf in ring:
+                ffi.release_witness_buffer(buf)
         self._levels, self._pool = {}, {}
 
     def proof_size_of_level(self, level, width=DEFAULT_TREE_BRANCHING_FACTOR):

@@ -21,10 +21,28 @@ std::vector<uint32_t> fri_arities(uint32_t degree_bits) {
   return a;
 }
 uint32_t ceil_log2(size_t x) { uint32_t k = 0; while ((size_t(1) << k) < x) k++; return k; }
-const int DEGREE[K_KINDS] = {0, 1, 1, 2, 3, 7};            // constraint degree per row kind: orders the gate list and forms the selector groups
-const uint32_t TAG[K_KINDS] = {QPGPU_GATE_NOOP, QPGPU_GATE_CONSTANT, QPGPU_GATE_PUBLIC_INPUT, QPGPU_GATE_BASESUM2, QPGPU_GATE_ARITHMETIC, QPGPU_GATE_POSEIDON};
-const uint64_t PARAM[K_KINDS] = {0, 2, 0, BASESUM_LIMBS, ARITH_OPS, 0};
+// per row kind: constraint degree (orders the gate list and forms the selector groups), serializer tag, parameters
+const int DEGREE[K_ALL_KINDS] = {0, 1, 1, 2, 3, 7, 3, 3, 2, 2, RA_BITS + 1, 1, 4, COSET_DEG};
+const uint32_t TAG[K_ALL_KINDS] = {QPGPU_GATE_NOOP, QPGPU_GATE_CONSTANT, QPGPU_GATE_PUBLIC_INPUT, QPGPU_GATE_BASESUM2, QPGPU_GATE_ARITHMETIC, QPGPU_GATE_POSEIDON,
+                                   QPGPU_GATE_ARITHMETIC_EXTENSION, QPGPU_GATE_MUL_EXTENSION, QPGPU_GATE_REDUCING, QPGPU_GATE_REDUCING_EXTENSION, QPGPU_GATE_RANDOM_ACCESS,
+                                   QPGPU_GATE_POSEIDON_MDS, QPGPU_GATE_EXPONENTIATION, QPGPU_GATE_COSET_INTERPOLATION};
+const uint64_t PARAM[K_ALL_KINDS] = {0, 2, 0, BASESUM_LIMBS, ARITH_OPS, 0, ARITH_EXT_OPS, 13, REDUCING_COEFFS, REDUCING_EXT_COEFFS, RA_BITS, 0, EXP_BITS, COSET_BITS};
+const uint32_t PARAM2[K_ALL_KINDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, RA_COPIES, 0, 0, COSET_DEG};
+const uint32_t PARAM3[K_ALL_KINDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, RA_EXTRA, 0, 0, 0};
 const uint32_t NUM_QUERIES = 28, CAP_HEIGHT = 4, POW_BITS = 16, RATE_BITS = 3;
+}
+
+const u64* Builder::coset_domain() {
+  static const std::vector<u64> dom = [] { std::vector<u64> d; u64 wg = gl_root(COSET_BITS), x = 1; for (int i = 0; i < COSET_NP; i++) { d.push_back(x); x = gl_mul(x, wg); } return d; }();
+  return dom.data();
+}
+const u64* Builder::coset_weights() {
+  static const std::vector<u64> w = [] {
+    const u64* dom = coset_domain(); std::vector<u64> out;
+    for (int i = 0; i < COSET_NP; i++) { u64 d = 1; for (int j = 0; j < COSET_NP; j++) if (j != i) d = gl_mul(d, gl_sub(dom[i], dom[j])); out.push_back(gl_inv(d)); }
+    return out;
+  }();
+  return w.data();
 }
 
 static double now_ms();
@@ -78,7 +96,7 @@ void Builder::build() {
         case OP_EXTINV: in = {op.a, op.b}; break;
         case OP_SPLIT: in = {op.out}; break;
         case OP_POSEIDON: for (int i = 0; i < 13; i++) in.push_back(op.out + i); break;
-        default: break;
+        default: special_reads(op, [&](Target t) { in.push_back(t); }); break;
       }
     };
     auto writes = [&](const Op& op, std::vector<Target>& out) {
@@ -88,6 +106,7 @@ void Builder::build() {
         case OP_LOHI: case OP_EXTINV: out = {op.out, op.c}; break;
         case OP_SPLIT: for (int l = 0; l < BASESUM_LIMBS; l++) out.push_back(op.out + 1 + l); break;
         case OP_POSEIDON: for (int i = 0; i < 12; i++) out.push_back(op.out + 13 + i); break;
+        default: special_writes(op, [&](Target t) { out.push_back(t); }); break;
       }
     };
     std::vector<Target> tmp;
@@ -131,8 +150,10 @@ void Builder::build() {
 
   lapb("sigma");
   // gate list ordered by degree; selector groups as upstream forms them (a group grows while size + next degree < 8): [0,5), [5,6)
-  int gate_index[K_KINDS];
-  { std::vector<int> kinds; for (int i = 0; i < K_KINDS; i++) kinds.push_back(i);
+  int gate_index[K_ALL_KINDS];
+  { std::vector<int> kinds; for (int i = 0; i < K_KINDS; i++) kinds.push_back(i);            // the leaf set always; a recursion gate if the circuit has such a row
+    { bool used[K_ALL_KINDS] = {false}; for (size_t r = 0; r < gate_rows_; r++) used[row_kind_[r]] = true;
+      for (int i = K_KINDS; i < K_ALL_KINDS; i++) { gate_index[i] = -1; if (used[i]) kinds.push_back(i); } }
     std::stable_sort(kinds.begin(), kinds.end(), [](int a, int b) { return DEGREE[a] < DEGREE[b]; });
     for (size_t i = 0; i < kinds.size(); i++) gate_index[kinds[i]] = (int)i;
     sel_idx_.assign(kinds.size(), 0); size_t start = 0;
@@ -142,7 +163,11 @@ void Builder::build() {
       for (size_t i = 0; i < size; i++) sel_idx_[start + i] = (uint32_t)(groups_.size() / 2);
       groups_.push_back((uint32_t)start); groups_.push_back((uint32_t)(start + size)); start += size;
     }
-    for (int kd : kinds) { qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = TAG[kd]; g.param = PARAM[kd]; gates_.push_back(g); } }
+    for (int kd : kinds) {
+      qpgpu_gate g; memset(&g, 0, sizeof g); g.tag = TAG[kd]; g.param = PARAM[kd]; g.param2 = PARAM2[kd]; g.param3 = PARAM3[kd];
+      if (kd == K_COSET) { g.table = coset_weights(); g.table_len = COSET_NP; }
+      gates_.push_back(g);
+    } }
   const int nsel = (int)(groups_.size() / 2);                  // 2 for this gate set; NC = nsel + 2 local constants
   k_is_.resize(R); { u64 x = 1; for (int j = 0; j < R; j++) { k_is_[j] = x; x = gl_mul(x, GL_GEN); } }
   constants_sigmas_.assign((size_t)(nsel + 2 + R) * n_, 0);
@@ -310,6 +335,7 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
         wset(op.out, gl_mul(a, ni)); wset(op.c, gl_mul(gl_sub(0, b), ni));
         break;
       }
+      default: special_eval(op, wget, wset); break;               // the recursive verifier's gate rows
     }
   };
   const int nthr = parallel_ok_ ? std::max(1, std::min(threads, 32)) : 1;

@@ -336,8 +336,14 @@ extern "C" int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, u
   u64 s = seed * 0x9E3779B97F4A7C15ULL + 0x5157;
   auto next = [&]() { u64 z = (s += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
   auto felt = [&]() { u64 v = next(); return v >= P ? v - P : v; };
+  const bool recursion_gates = (zero_knowledge & 2) != 0;        // bit 1: the program also draws from the recursive verifier's gates
+  zero_knowledge &= 1;
   std::unique_ptr<qpc_circuit> c(new qpc_circuit(QPC_AGGREGATION + 1, zero_knowledge != 0));
   Builder& b = c->b;
+  struct E2 { u64 a, b; };
+  auto emul = [](E2 x, E2 y) { return E2{gl_add(gl_mul(x.a, y.a), gl_mul(7, gl_mul(x.b, y.b))), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a))}; };
+  auto eadd = [](E2 x, E2 y) { return E2{gl_add(x.a, y.a), gl_add(x.b, y.b)}; };
+  auto escale = [](E2 x, u64 k) { return E2{gl_mul(x.a, k), gl_mul(x.b, k)}; };
   std::vector<Target> t; std::vector<u64> v;                    // targets and their native values
   for (uint32_t i = 0; i < num_inputs; i++) {
     u64 x = next() % 5 == 0 ? next() % 4 : (next() % 3 == 0 ? next() & 0xFFFFFFFFULL : felt());      // bits, 32-bit values and full field elements
@@ -348,6 +354,63 @@ extern "C" int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, u
   auto as_bool = [&](size_t i) { BoolT r = b.is_equal(t[i], b.zero()); return std::make_pair(r, (u64)(v[i] == 0)); };   // a boolean derived from any value
   for (uint32_t op = 0; op < num_ops; op++) {
     const size_t i = pick(), j = pick(), k = pick();
+    auto pick_ext = [&](Ext2& t2, E2& v2) { const size_t x = pick(), y = pick(); t2 = Ext2{t[x], t[y]}; v2 = E2{v[x], v[y]}; };
+    if (recursion_gates && next() % 3 == 0) {
+      switch (next() % 7) {
+        case 0: {                                                   // ArithmeticExtension
+          Ext2 m0, m1, ad; E2 v0, v1, va; pick_ext(m0, v0); pick_ext(m1, v1); pick_ext(ad, va);
+          const u64 k0 = next() % 3 == 0 ? next() % 2 : felt(), k1 = next() % 3 == 0 ? next() % 2 : felt();
+          const Ext2 o = b.arith_ext(k0, k1, m0, m1, ad); const E2 ov = eadd(escale(emul(v0, v1), k0), escale(va, k1));
+          push(o.a, ov.a); push(o.b, ov.b); break;
+        }
+        case 1: {                                                   // Reducing: 1 .. 100 base coefficients (one to three rows)
+          Ext2 al; E2 av; pick_ext(al, av);
+          const int cnt = 1 + (int)(next() % 100); std::vector<Target> cs; E2 acc{0, 0};
+          for (int q = 0; q < cnt; q++) { const size_t z = pick(); cs.push_back(t[z]); acc = eadd(emul(acc, av), E2{v[z], 0}); }
+          const Ext2 o = b.reduce_base(al, cs); push(o.a, acc.a); push(o.b, acc.b); break;
+        }
+        case 2: {                                                   // ReducingExtension: 1 .. 70 extension coefficients
+          Ext2 al; E2 av; pick_ext(al, av);
+          const int cnt = 1 + (int)(next() % 70); std::vector<Ext2> cs; E2 acc{0, 0};
+          for (int q = 0; q < cnt; q++) { Ext2 ct; E2 cv; pick_ext(ct, cv); cs.push_back(ct); acc = eadd(emul(acc, av), cv); }
+          const Ext2 o = b.reduce_ext(al, cs); push(o.a, acc.a); push(o.b, acc.b); break;
+        }
+        case 3: {                                                   // RandomAccess: index = four bits of a value
+          Target hi_, lo_; b.lohi_hint(t[i], lo_, hi_);
+          b.connect(b.arithmetic(u64(1) << 32, 1, hi_, b.one(), lo_), t[i]); b.range_check(hi_, 32);
+          std::vector<BoolT> bits = b.split_le(lo_, 32);
+          const int from = (int)(next() % 28);
+          Target idx = b.zero(); for (int q = 3; q >= 0; q--) idx = b.arithmetic(2, 1, idx, b.one(), bits[from + q].t);
+          const u64 iv = ((v[i] & 0xFFFFFFFFULL) >> from) & 15;
+          std::vector<Target> list; std::vector<u64> lv; const int len = next() % 4 == 0 ? 1 + (int)(next() % 16) : 16;
+          for (int q = 0; q < len; q++) { const size_t z = pick(); list.push_back(t[z]); lv.push_back(v[z]); }
+          push(b.random_access(idx, list), iv < lv.size() ? lv[iv] : 0); break;
+        }
+        case 4: {                                                   // PoseidonMds
+          Ext2 in[12], out[12]; u64 a[12], bb[12];
+          for (int q = 0; q < 12; q++) { E2 ev; pick_ext(in[q], ev); a[q] = ev.a; bb[q] = ev.b; }
+          b.poseidon_mds(in, out); mds_layer(a); mds_layer(bb);
+          for (int q = 0; q < 12; q += 5) { push(out[q].a, a[q]); push(out[q].b, bb[q]); }
+          break;
+        }
+        case 5: if (v[i]) {                                         // CosetInterpolation against a native Lagrange evaluation
+          Ext2 vals[16], pt; E2 vv[16], pv; for (int q = 0; q < 16; q++) pick_ext(vals[q], vv[q]); pick_ext(pt, pv);
+          const Ext2 o = b.coset_interpolate(t[i], vals, pt);
+          const u64* dom = Builder::coset_domain(); const u64* wg = Builder::coset_weights();
+          const E2 xs = escale(pv, gl_inv(v[i])); E2 sum{0, 0};
+          for (int q = 0; q < 16; q++) { E2 term = escale(vv[q], wg[q]); for (int r = 0; r < 16; r++) if (r != q) term = emul(term, E2{gl_sub(xs.a, dom[r]), xs.b}); sum = eadd(sum, term); }
+          push(o.a, sum.a); push(o.b, sum.b);
+        } break;
+        default: {                                                  // Exponentiation by up to 40 bits of a value
+          Target hi_, lo_; b.lohi_hint(t[j], lo_, hi_);
+          b.connect(b.arithmetic(u64(1) << 32, 1, hi_, b.one(), lo_), t[j]); b.range_check(hi_, 32);
+          std::vector<BoolT> bits = b.split_le(lo_, 32);
+          const int nb = 1 + (int)(next() % 32); bits.resize(nb);
+          push(b.exponentiate(t[i], bits), gl_pow(v[i], (v[j] & 0xFFFFFFFFULL) & ((u64(1) << nb) - 1))); break;
+        }
+      }
+      continue;
+    }
     switch (next() % 16) {
       case 0: push(b.add(t[i], t[j]), gl_add(v[i], v[j])); break;
       case 1: push(b.sub(t[i], t[j]), gl_sub(v[i], v[j])); break;

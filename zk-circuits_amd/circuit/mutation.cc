@@ -47,7 +47,8 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
       case OP_EXTINV: in[0] = op.a; in[1] = op.b; return 2;
       case OP_SPLIT: in[0] = op.out; return 1;
       case OP_POSEIDON: for (int i = 0; i < 13; i++) in[i] = op.out + i; return 13;
-      default: return 0;
+      case OP_CONST: return 0;
+      default: { int k = 0; special_reads(op, [&](Target t) { in[k++] = t; }); return k; }
     }
   };
   // evaluates `op` on class values `v`; writes (target, value) pairs, returns their number
@@ -70,6 +71,12 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
         const u64 a = g(op.a), b = g(op.b), norm = gl_sub(gl_sqr(a), gl_mul(7, gl_sqr(b))), ni = norm ? gl_inv(norm) : 0;
         wt[0] = op.out; wv[0] = gl_mul(a, ni); wt[1] = op.c; wv[1] = gl_mul(gl_sub(0, b), ni); return 2;
       }
+      default: {                                           // the recursive verifier's gate rows: one definition with generate() (builder.h special_eval);
+        int k = 0;                                         // a later write to the same target replaces the earlier one, reads see the row's own writes
+        special_eval(op, [&](Target t) { for (int j = k; j-- > 0;) if (wt[j] == t) return wv[j]; return g(t); },
+                     [&](Target t, u64 x) { wt[k] = t; wv[k] = x; k++; });
+        return k;
+      }
     }
     return 0;
   };
@@ -78,7 +85,7 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
   std::vector<int64_t> writer(ncls_, NOBODY);
   for (Target t : inputs_) writer[cls_[t]] = -1;
   for (const Op& op : ops_) if (op.kind == OP_CONST) writer[cls_[op.out]] = -1;
-  Target wt[64]; u64 wv[64]; Target rd[16];
+  Target wt[192]; u64 wv[192]; Target rd[192];
   { std::vector<u64> dummy(ncls_, 0);
     for (size_t i = 0; i < ops_.size(); i++) {
       if (ops_[i].kind == OP_CONST) continue;
@@ -202,13 +209,13 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
   // ---- hint mutations
   for (size_t h = first; h < hint_ops.size() && out.size() < max_count; h += step) {
     const uint32_t k = hint_ops[h]; const Op& hop = ops_[k];
-    Target ht[64]; u64 hv[64];
+    Target ht[192]; u64 hv[192];
     const int hk = eval(hop, val0.data(), ht, hv);                          // the honest outputs
     const uint32_t nmodes = hop.kind == OP_INV ? 3 : hop.kind == OP_LOHI ? 5 : hop.kind == OP_EXTINV ? 4 : 2;
     for (uint32_t mode = 0; mode < nmodes; mode++) {
       if (!(modes_mask >> mode & 1)) continue;
       u64 s = seed ^ (h * 0x100000001B3ULL + mode * 0x9E37ULL);
-      u64 mv[64]; memcpy(mv, hv, sizeof(u64) * (size_t)hk);
+      u64 mv[192]; memcpy(mv, hv, sizeof(u64) * (size_t)hk);
       bool skip = false;
       switch (hop.kind) {
         case OP_INV:
@@ -250,9 +257,12 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
         } else {                                                            // same outputs as in the honest run: a conflict iff its class moved
           int nw; Target first_t;
           switch (op.kind) { case OP_SPLIT: nw = BASESUM_LIMBS; first_t = op.out + 1; break; case OP_POSEIDON: nw = 12; first_t = op.out + 13; break;
-                             case OP_LOHI: case OP_EXTINV: nw = -2; first_t = op.out; break; default: nw = 1; first_t = op.out; }
-          if (nw == -2) { for (Target t : {op.out, op.c}) { const uint32_t c = cls_[t]; if (dirty[c] && writer[c] != (int64_t)i) res.conflicts++; } }
-          else for (int j = 0; j < nw; j++) { const uint32_t c = cls_[first_t + j]; if (dirty[c] && writer[c] != (int64_t)i) res.conflicts++; }
+                             case OP_LOHI: case OP_EXTINV: nw = -2; first_t = op.out; break;
+                             case OP_ARITH: case OP_INV: nw = 1; first_t = op.out; break; default: nw = -3; first_t = op.out; }
+          auto chk = [&](Target t) { const uint32_t c = cls_[t]; if (dirty[c] && writer[c] != (int64_t)i) res.conflicts++; };
+          if (nw == -2) { chk(op.out); chk(op.c); }
+          else if (nw == -3) special_writes(op, chk);
+          else for (int j = 0; j < nw; j++) chk(first_t + j);
         }
       }
       const std::string e = finish(res, own, false, (int64_t)k, hk, ht, mv);

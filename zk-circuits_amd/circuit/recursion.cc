@@ -13,6 +13,8 @@
 #include "../csrc/proof_format.h"
 #include "builder.h"
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 namespace qpc {
 using namespace qp;
@@ -236,6 +238,8 @@ static void eval_gate_constraints(G& g, const Inner& in, const ExtT* consts, con
 void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierDataT& vd) {
   G g{b};
   const int nch = in.nch; const size_t n = size_t(1) << in.log_n;
+  static const bool report = getenv("QPC_TIMING") != nullptr; size_t rows_mark = b.num_rows_so_far();
+  auto section = [&](const char* what) { if (report) { const size_t r = b.num_rows_so_far(); fprintf(stderr, "  verify_proof %-22s %6zu rows\n", what, r - rows_mark); rows_mark = r; } };
   // witness generation replays a proof's transcript / vanishing identity / reduced openings as one stage-1 segment and each of its queries
   // as a stage-2 segment (builder.h begin_segment): the children of a node, and then all their queries, are independent of each other
   b.begin_segment(1);
@@ -272,6 +276,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
     b.assert_zero(b.mul(b.is_equal(hi, b.constant(0xFFFFFFFFULL)).t, lo));
     lob.resize(in.log_N); index_bits.push_back(lob);
   }
+  section("transcript + indices");
   // ---- openings by name (proof order: constants|sigmas | wires | zs | zs_next | partial products | quotient)
   const ExtT* o_cs = pf.op.data(); const ExtT* o_wires = o_cs + in.S; const ExtT* o_zs = o_wires + in.W; const ExtT* o_zs_next = o_zs + nch;
   const ExtT* o_pp = o_zs_next + nch; const ExtT* o_q = o_pp + (size_t)nch * in.npp; const ExtT* o_sigmas = o_cs + in.d.num_constants;
@@ -307,6 +312,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
       g.assert_eq(van, g.mul(zh, qv));
     }
   }
+  section("vanishing identity");
   // ---- FRI: reduced openings, then per query the initial combination, the layer folds, the final polynomial and every Merkle opening
   const size_t n0 = (size_t)in.S + in.W + in.Zp + in.Q;
   std::vector<ExtT> apow(n0 + 1); apow[0] = g.cst(1); for (size_t i = 1; i <= n0; i++) apow[i] = g.mul(apow[i - 1], fri_alpha);
@@ -321,6 +327,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
   const size_t unsalted[4] = {(size_t)in.S, (size_t)in.W, (size_t)in.Zp, (size_t)in.Q};
   const int path = in.log_N - in.cap_h;
   const u64 wN = gl_root(in.log_N);
+  section("reduced openings");
   for (uint32_t qi = 0; qi < in.d.fri_num_queries; qi++) {
     b.begin_segment(2);
     const QueryT& q = pf.q[qi]; const std::vector<BoolT>& bits = index_bits[qi];
@@ -370,6 +377,7 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
     (void)lg;
   }
   b.end_segment();
+  section("queries");
 }
 
 } // namespace qpc

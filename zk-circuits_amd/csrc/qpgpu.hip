@@ -854,6 +854,14 @@ int qpgpu_profile_get(int id, uint64_t* launches, double* ms, double* alg_bytes)
   *launches = g_prof[id].launches; *ms = g_prof[id].ms; *alg_bytes = g_prof[id].bytes; return 0;
 }
 
+int qpgpu_host_alloc(size_t bytes, void** out) { return abi_guard([&]() -> int {
+  if (!out || bytes == 0) return set_err(QPGPU_ERR_ARG, "null argument");
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocPortable));
+  *out = p; return 0;
+}); }
+void qpgpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
                 const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len) { return abi_guard([&]() -> int {
   if (!c || !wires || !public_inputs || !out) return set_err(QPGPU_ERR_ARG, "null argument");

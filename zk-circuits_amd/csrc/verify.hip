@@ -22,6 +22,8 @@
 #include <thread>
 #include <atomic>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +32,39 @@
 
 namespace qp { extern thread_local std::string g_last_error; int set_err(int code, const std::string& m); }
 using namespace qp;
+
+// Host worker threads of a verifier, kept for the life of the handle: a batch runs two parallel passes (the algebra of every proof, then
+// staging their openings), and spawning up to 2 x 16 threads per call cost more than a single proof's whole host pass.
+struct WorkerPool {
+  std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, done_cv;
+  std::function<void()> job; uint64_t gen = 0; size_t tickets = 0, pending = 0; bool stop = false;
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || (gen != seen && tickets > 0); });
+      if (stop) return;
+      seen = gen; tickets--;
+      std::function<void()> j = job;
+      lk.unlock();
+      try { j(); } catch (...) {}
+      lk.lock();
+      if (--pending == 0) done_cv.notify_all();
+    }
+  }
+  // runs `body` on n threads (n - 1 of the pool + the caller) and returns when all have finished; body hands out its own work items
+  void run(size_t n, const std::function<void()>& body) {
+    size_t helpers = n > 1 ? n - 1 : 0;
+    { std::lock_guard<std::mutex> lk(mu);
+      while (th.size() < helpers) { try { th.emplace_back([this] { worker(); }); } catch (...) { break; } }      // fewer workers if threads cannot be created
+      helpers = std::min(helpers, th.size());
+      if (helpers) { job = body; gen++; tickets = helpers; pending = helpers; } }
+    if (helpers) cv.notify_all();
+    body();
+    if (helpers) { std::unique_lock<std::mutex> lk(mu); done_cv.wait(lk, [&] { return pending == 0; }); }
+  }
+  ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); }
+};
 
 struct qpgpu_verifier {
   int device = 0;
@@ -43,6 +78,7 @@ struct qpgpu_verifier {
   void* d_stage = nullptr; size_t d_stage_bytes = 0;
   u64* h_stage = nullptr; size_t h_stage_words = 0;        // pinned host staging buffer of the openings
   hipStream_t streams[4 + MAX_FRI_LAYERS] = {};            // one per tree kind (their openings are checked concurrently)
+  WorkerPool pool;                                         // host threads of the batch passes (created on the first batch that needs them)
 };
 
 namespace {
@@ -511,8 +547,7 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
       }
     };
     size_t nthreads = (size_t)qp::usable_cpus(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
-    std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
-    body(); for (auto& t : th) t.join();
+    v->pool.run(nthreads, body);
   }
   vlap("host");
   // ---- device pass: all Merkle openings of the proofs that survived. One staging buffer for every tree kind, one upload, one launch per
@@ -568,8 +603,7 @@ int qpgpu_verify_batch(qpgpu_verifier* v, const uint8_t* proofs, size_t proof_st
         }
       };
       size_t nthreads = (size_t)qp::usable_cpus(); if (nthreads > 16) nthreads = 16; if (nthreads > count) nthreads = count; if (nthreads < 1) nthreads = 1;
-      std::vector<std::thread> th; for (size_t t = 1; t < nthreads; t++) { try { th.emplace_back(body); } catch (...) { break; } }
-      body(); for (auto& t : th) t.join(); }
+      v->pool.run(nthreads, body); }
     const size_t bytes = words * 8 + ok_words * 4 + 64;
     if (v->d_stage_bytes < bytes) { if (v->d_stage) (void)hipFree(v->d_stage); v->d_stage = nullptr; v->d_stage_bytes = 0; V_TRY(hipMalloc(&v->d_stage, bytes + bytes / 4)); v->d_stage_bytes = bytes + bytes / 4; }
     for (int k = 0; k < kinds; k++) if (!v->streams[k]) V_TRY(hipStreamCreateWithFlags(&v->streams[k], hipStreamNonBlocking));

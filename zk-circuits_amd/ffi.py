@@ -121,6 +121,15 @@ def lib():
         L.qpgpu_verifier_proof_size.restype = ctypes.c_size_t
         L.qpgpu_verifier_proof_size.argtypes = [ctypes.c_void_p]
         L.qpgpu_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32)]
+        L.qpgpu_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_host_free.argtypes = [ctypes.c_void_p]
+        L.qpgpu_host_free.restype = None
+        L.qpgpu_comm_unique_id.argtypes = [ctypes.c_char_p]
+        L.qpgpu_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.qpgpu_comm_destroy.argtypes = [ctypes.c_void_p]
+        L.qpgpu_comm_destroy.restype = None
+        L.qpgpu_comm_rank.argtypes = L.qpgpu_comm_world.argtypes = [ctypes.c_void_p]
+        L.qpgpu_gather_proofs.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p]
         # ---- include/qpgpu_internal.h
         L.qpgpu_replay_transcript.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t, u64p, ctypes.c_size_t]
         L.qpgpu_test_verify_host.argtypes = [ctypes.POINTER(CircuitDesc), ctypes.c_char_p, ctypes.c_size_t]
@@ -294,13 +303,13 @@ class BuiltCircuit:
         self.num_inputs = circuit_lib().qpc_circuit_num_inputs(h)
 
     @classmethod
-    def random_program(cls, seed, zero_knowledge=False, num_inputs=12, num_ops=300):
+    def random_program(cls, seed, zero_knowledge=False, num_inputs=12, num_ops=300, recursion_gates=False):
         """Test hook (include/qpcircuit_internal.h): a circuit of random builder operations; returns (circuit, input values, natively computed
         values of its public inputs)."""
         self = cls.__new__(cls)
         h = ctypes.c_void_p()
         inputs = np.zeros(num_inputs, dtype=np.uint64); expected = np.zeros(8 * num_ops + 64, dtype=np.uint64); n = ctypes.c_size_t()
-        circuit_check(circuit_lib().qpc_test_random_circuit(seed, 1 if zero_knowledge else 0, num_inputs, num_ops, ctypes.byref(h), ptr(inputs), ptr(expected),
+        circuit_check(circuit_lib().qpc_test_random_circuit(seed, (1 if zero_knowledge else 0) | (2 if recursion_gates else 0), num_inputs, num_ops, ctypes.byref(h), ptr(inputs), ptr(expected),
                                                             len(expected), ctypes.byref(n)))
         self.handle, self.kind = h, -1
         self.desc = circuit_lib().qpc_circuit_desc(h).contents
@@ -559,6 +568,97 @@ class CircuitPackage:
         try:
             if self.h:
                 qpgpu().qpgpu_package_free(self.h); self.h = None
+        except Exception:
+            pass
+
+
+class _PinnedBlock:
+    """Owner of one qpgpu_host_alloc block (freed when the last numpy view of it goes away)."""
+
+    def __init__(self, ptr_):
+        self.ptr = ptr_
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().qpgpu_host_free(self.ptr); self.ptr = None
+        except Exception:
+            pass
+
+
+def witness_buffer(num_wires, n, num_public_inputs, pinned=True):
+    """A reusable (wires [num_wires][n], public_inputs) pair for BuiltCircuit.witness(out=...). With `pinned` the matrix lives in page-locked
+    host memory (qpgpu_host_alloc), so qpgpu_prove(_batch) uploads it with one DMA transfer instead of staging it through bounce buffers on
+    the proving thread; if page-locked memory cannot be had (no device in this process) it is ordinary memory."""
+    pis = np.zeros(num_public_inputs, dtype=np.uint64)
+    if pinned:
+        try:
+            p = ctypes.c_void_p()
+            if lib().qpgpu_host_alloc(num_wires * n * 8, ctypes.byref(p)) == 0 and p.value:
+                block = _PinnedBlock(p.value)
+                raw = (ctypes.c_uint64 * (num_wires * n)).from_address(p.value)
+                wires = np.frombuffer(raw, dtype=np.uint64).reshape(num_wires, n)
+                _PINNED_OWNERS[wires.ctypes.data] = block          # keeps the block alive as long as the entry stays (release_witness_buffer drops it)
+                return wires, pis
+        except Exception:
+            pass
+    return np.empty((num_wires, n), dtype=np.uint64), pis
+
+
+_PINNED_OWNERS = {}
+
+
+def release_witness_buffer(buf):
+    """Frees the page-locked block behind a witness_buffer (no-op for ordinary memory). The arrays must not be used afterwards."""
+    _PINNED_OWNERS.pop(buf[0].ctypes.data, None)
+
+
+COMM_ID_BYTES = 128          # include/qpgpu.h QPGPU_COMM_ID_BYTES
+
+
+class ProofComm:
+    """qpgpu_comm (include/qpgpu.h): the native RCCL communicator of this rank for the all-gather of proof blobs. `unique_id` (rank 0
+    makes it with ProofComm.unique_id()) reaches the other ranks out of band; creation is collective."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        gpu_check(qpgpu().qpgpu_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, rank, world, unique_id, device=0):
+        L = qpgpu()
+        assert len(unique_id) == COMM_ID_BYTES
+        self.ctx = ctypes.c_void_p()
+        gpu_check(L.qpgpu_ctx_create(device, ctypes.byref(self.ctx)))
+        self.h = ctypes.c_void_p()
+        rc = L.qpgpu_comm_create(self.ctx, rank, world, bytes(unique_id), ctypes.byref(self.h))
+        if rc != 0:
+            L.qpgpu_ctx_destroy(self.ctx); self.ctx = None
+            gpu_check(rc)
+        self.rank, self.world = rank, world
+
+    def gather(self, local_proofs, proof_size):
+        """Every rank contributes len(local_proofs) blobs of proof_size bytes (the same count everywhere); returns all of them in rank order."""
+        k = len(local_proofs)
+        if k == 0:
+            return []
+        flat = b"".join(bytes(p) for p in local_proofs)
+        assert len(flat) == k * proof_size
+        out = ctypes.create_string_buffer(k * proof_size * self.world)
+        gpu_check(qpgpu().qpgpu_gather_proofs(self.h, flat, k, proof_size, out))
+        raw = out.raw
+        return [raw[i * proof_size:(i + 1) * proof_size] for i in range(k * self.world)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            qpgpu().qpgpu_comm_destroy(self.h); self.h = None
+        if getattr(self, "ctx", None):
+            qpgpu().qpgpu_ctx_destroy(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
