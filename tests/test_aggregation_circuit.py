@@ -112,7 +112,7 @@ def test_argument_errors(vote_leaf, level1):
         node.aggregation_targets(oc.cap(), inner.desc.circuit_digest, [leaf])
     with pytest.raises(CircuitError, match="proof length"):
         node.aggregation_targets(oc.cap(), inner.desc.circuit_digest, [leaf[:-8], leaf[:-8]])
-    with pytest.raises(CircuitError, match="leaf gate set only"):
+    with pytest.raises(CircuitError, match="does not cover gate tag"):
         rt = SynthCircuit("RT")                                                   # (kept alive: the descriptor points into it)
         BuiltCircuit.aggregation(rt.desc, 2)                                      # recursion-shaped synthetic circuit: gates outside the leaf set
     leaf_shape = BuiltCircuit(QPC_WORMHOLE, False)

@@ -23,7 +23,9 @@ pkg = importlib.import_module("zk-circuits_amd")
 th = pkg.test_helpers
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-KINDS = {2: "inverse", 3: "base-sum limbs", 5: "extension inverse", 6: "lo/hi halves", 100: "input flip"}
+KINDS = {2: "inverse", 3: "base-sum limbs", 5: "extension inverse", 6: "lo/hi halves", 100: "input flip",
+         7: "ArithmeticExtension output", 8: "Reducing accumulators", 9: "ReducingExtension accumulators", 10: "RandomAccess bits / claimed element",
+         11: "PoseidonMds outputs", 12: "CosetInterpolation shifted point / intermediates / value", 13: "Exponentiation intermediates"}
 VERDICTS = {0: "killed", 1: "benign", 2: "SURVIVED", 3: "INCONSISTENT", 4: "skipped", 5: "no cell", 6: "blocked"}
 
 
@@ -138,10 +140,11 @@ def test_aggregation_node_every_hint_on_the_reference_golden_proof():
     w, p = node.witness(x)
     assert check_witness(OracleCircuit(node.desc), w, p) is None
     res, stats = sweep(node, x, 0, full_every=997)
-    t = assert_sound(res, "aggregation node over the golden proof", min_hints=500)
+    t = assert_sound(res, "aggregation node over the golden proof", min_hints=2500)
     assert stats["full"] >= 5
     kinds = {k for k, _ in t}
-    assert {"inverse", "extension inverse", "lo/hi halves", "base-sum limbs"} <= kinds, kinds
+    assert {"inverse", "extension inverse", "lo/hi halves", "base-sum limbs", "ArithmeticExtension output", "Reducing accumulators", "ReducingExtension accumulators",
+            "RandomAccess bits / claimed element", "PoseidonMds outputs", "CosetInterpolation shifted point / intermediates / value"} <= kinds, kinds
 
 
 def test_aggregation_node_rejects_every_flipped_proof_cell():

@@ -340,7 +340,10 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
   };
   const int nthr = parallel_ok_ ? std::max(1, std::min(threads, 32)) : 1;
   std::vector<Worker> workers((size_t)nthr);
-  auto run_list = [&](const std::vector<uint32_t>& idx, Worker& wk) { for (uint32_t i : idx) { exec(ops_[i], wk); if (!wk.err.empty()) return; } };
+  static const bool opstat = getenv("QPC_OPSTAT") != nullptr; static double kind_ms[32]; static long kind_n[32];
+  auto run_list = [&](const std::vector<uint32_t>& idx, Worker& wk) {
+    if (opstat) { for (uint32_t i : idx) { const double t0 = now_ms(); exec(ops_[i], wk); kind_ms[ops_[i].kind] += now_ms() - t0; kind_n[ops_[i].kind]++; if (!wk.err.empty()) return; } return; }
+    for (uint32_t i : idx) { exec(ops_[i], wk); if (!wk.err.empty()) return; } };
   auto run_stage = [&](const std::vector<std::vector<uint32_t>>& segs) {           // segments of one stage over the workers (dynamic hand-out)
     if (segs.empty()) return;
     std::atomic<size_t> next{0};
@@ -359,6 +362,7 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
   } else {
     for (const Op& op : ops_) { exec(op, workers[0]); if (!workers[0].err.empty()) break; }     // program order
   }
+  if (opstat) { for (int k = 0; k < 32; k++) if (kind_n[k]) { fprintf(stderr, "  op kind %2d: %7ld ops %8.3f ms\n", k, kind_n[k], kind_ms[k]); kind_ms[k] = 0; kind_n[k] = 0; } }
   err = first_error();
   if (!err.empty()) return err;
   std::vector<u64> ptrace;

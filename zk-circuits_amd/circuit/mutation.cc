@@ -29,7 +29,7 @@ u64 felt(u64& s) { u64 v = splitmix(s); return v >= P ? v - P : v; }
 
 size_t Builder::num_hints() const {
   size_t k = 0;
-  for (const Op& op : ops_) if (op.kind == OP_INV || op.kind == OP_LOHI || op.kind == OP_EXTINV || op.kind == OP_SPLIT) k++;
+  for (const Op& op : ops_) if (op.kind == OP_INV || op.kind == OP_LOHI || op.kind == OP_EXTINV || op.kind == OP_SPLIT || is_special(op.kind)) k++;
   return k;
 }
 
@@ -139,7 +139,9 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
   { std::vector<uint32_t> pos(cstart.begin(), cstart.end() - 1); for (size_t i = 0; i < fill_dst_.size(); i++) ccell[pos[fill_cls_[i]]++] = fill_dst_[i]; }
   std::vector<uint32_t> pops; for (size_t i = 0; i < ops_.size(); i++) if (ops_[i].kind == OP_POSEIDON) pops.push_back((uint32_t)i);
   std::vector<uint32_t> hint_ops;
-  for (size_t i = 0; i < ops_.size(); i++) { const uint8_t k = ops_[i].kind; if (k == OP_INV || k == OP_LOHI || k == OP_EXTINV || k == OP_SPLIT) hint_ops.push_back((uint32_t)i); }
+  // hint-bearing operations: the classic hints, and every operation of a special gate (its outputs and auxiliary wires — accumulators,
+  // RandomAccess bits, the shifted interpolation point, intermediates — are generator-supplied and pinned by the row's own constraints)
+  for (size_t i = 0; i < ops_.size(); i++) { const uint8_t k = ops_[i].kind; if (k == OP_INV || k == OP_LOHI || k == OP_EXTINV || k == OP_SPLIT || is_special(k)) hint_ops.push_back((uint32_t)i); }
 
   std::vector<u64> val(val0), pis(npi ? npi : 1), scratch;
   std::vector<uint8_t> dirty(ncls_, 0), rowmark(n, 0);
@@ -212,6 +214,7 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
     Target ht[192]; u64 hv[192];
     const int hk = eval(hop, val0.data(), ht, hv);                          // the honest outputs
     const uint32_t nmodes = hop.kind == OP_INV ? 3 : hop.kind == OP_LOHI ? 5 : hop.kind == OP_EXTINV ? 4 : 2;
+    if (hk == 0) continue;
     for (uint32_t mode = 0; mode < nmodes; mode++) {
       if (!(modes_mask >> mode & 1)) continue;
       u64 s = seed ^ (h * 0x100000001B3ULL + mode * 0x9E37ULL);
@@ -237,6 +240,11 @@ std::string Builder::mutation_sweep(const u64* inputs, const uint8_t* blinding_k
           else { mv[0] = felt(s); mv[1] = felt(s); if (mv[0] == hv[0] && mv[1] == hv[1]) mv[0] = gl_add(mv[0], 1); }
           break;
         case OP_SPLIT: { const int l = (int)(splitmix(s) % BASESUM_LIMBS); mv[l] = mode == 0 ? 1 - hv[l] : gl_add(hv[l], 2); break; }   // another bit / not a bit at all
+        default: {                                            // a special gate's row: one of the wires its generator writes, +1 / a random value
+          const int l = mode == 0 ? 0 : (int)(splitmix(s) % (u64)hk);
+          if (mode == 0) mv[l] = gl_add(hv[l], 1); else { mv[l] = felt(s); if (mv[l] == hv[l]) mv[l] = gl_add(mv[l], 1); }
+          break;
+        }
       }
       if (skip) { out.push_back(MutationResult{(uint32_t)h, hop.kind, mode, 4, 0, 0, 0}); continue; }
       MutationResult res{(uint32_t)h, hop.kind, mode, 0, 0, 0, 0};

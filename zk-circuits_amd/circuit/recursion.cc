@@ -2,13 +2,17 @@
 // aggregate_chunk of the reference (wormhole/aggregator/src/circuits/tree.rs:106-143: add_virtual_verifier_data, add_virtual_proof_with_pis,
 // verify_proof, register_public_inputs, set_verifier_data_target / set_proof_with_pis_target). Host-only C++.
 //
-// qp-plonky2's recursive verifier (and the special gates it is built from) is not on disk, so this is this repo's own in-circuit verifier,
-// a gate-for-gate restatement of this repo's host verifier (csrc/verify.hip: transcript, vanishing identity at zeta, FRI openings, folds and
-// Merkle paths; formulas SURVEY.md App. A.4-A.9) on the builder's leaf gate set (Poseidon / Arithmetic / BaseSum / Constant): extension-field
-// products are four Arithmetic slots, Merkle steps use the Poseidon gate's swap wire, table look-ups are indicator sums. A node circuit is
-// therefore larger than upstream's (2^14 rows for two children, 2^15 with zero knowledge, instead of ~2^12-2^13), its layout is unpinned like every circuit of this
-// builder, and what it proves is the same: "each child proof verifies against the given verifier data, and these are their public inputs".
-// The inner circuit must use the leaf gate set (a leaf circuit or another node circuit built here).
+// qp-plonky2's recursive verifier is not on disk, so this is this repo's own in-circuit verifier, a restatement of this repo's host
+// verifier (csrc/verify.hip: transcript, vanishing identity at zeta, FRI openings, folds and Merkle paths; formulas SURVEY.md App. A.4-A.9)
+// on the gates upstream's recursive verifier is built from: extension-field products on ArithmeticExtension rows, the
+// alpha-reductions of a query's 255 row values / of the 257 openings / of the vanishing terms on Reducing / ReducingExtension rows, cap and
+// coset-position look-ups on RandomAccess rows, the arity-16 folds on CosetInterpolation rows, the Poseidon gate's MDS layers (vanishing
+// identity of the child) on PoseidonMds rows, Merkle steps on the Poseidon gate's swap wire. Two children give about 9.2 k rows, of which
+// 6.6 k are the Poseidon rows of the 2 x 28 x 7 Merkle openings — those are the proof format's, no gate set removes them, and they alone
+// keep a two-child node above 2^13 (and a zero-knowledge node, with its 8,326 blinding rows, above 2^14). QPC_NODE_LEAF_GATES=1 builds the
+// round-2 form on the leaf gate set only (14 k rows; kept for comparison). The layout is unpinned like every circuit of this builder; what
+// a node proves is the reference's statement: "each child proof verifies against the given verifier data, and these are their public inputs".
+// The inner circuit may use the leaf gate set and the gates named above (a leaf circuit or another node circuit built here).
 #include "../../include/qpcircuit.h"
 #include "../csrc/proof_format.h"
 #include "builder.h"
@@ -19,16 +23,21 @@
 namespace qpc {
 using namespace qp;
 
-struct ExtT { Target a, b; };
+typedef Ext2 ExtT;
 
 struct G {                                   // F_{p^2} = F_p[X]/(X^2 - 7) over builder targets
-  Builder& b;
+  Builder& b; bool rg;                       // rg: products on ArithmeticExtension rows (ten per row) instead of four Arithmetic slots each
   ExtT cst(u64 x, u64 y = 0) { return {b.constant(x), b.constant(y)}; }
   ExtT base(Target t) { return {t, b.zero()}; }
   ExtT add(ExtT x, ExtT y) { return {b.add(x.a, y.a), b.add(x.b, y.b)}; }
   ExtT sub(ExtT x, ExtT y) { return {b.sub(x.a, y.a), b.sub(x.b, y.b)}; }
-  ExtT mul_add(ExtT x, ExtT y, ExtT z) {     // x*y + z: four slots
+  ExtT mul_add(ExtT x, ExtT y, ExtT z) {     // x*y + z: one ArithmeticExtension operation, or four Arithmetic slots
+    if (rg) return b.arith_ext(1, 1, x, y, z);
     return {b.arithmetic(1, 1, x.a, y.a, b.arithmetic(7, 1, x.b, y.b, z.a)), b.arithmetic(1, 1, x.b, y.a, b.arithmetic(1, 1, x.a, y.b, z.b))};
+  }
+  ExtT kmul_add(u64 k0, ExtT x, ExtT y, u64 k1, ExtT z) {   // k0*x*y + k1*z
+    if (rg) return b.arith_ext(k0, k1, x, y, z);
+    return scale_add(mul(x, y), k0, scale(z, k1));
   }
   ExtT mul(ExtT x, ExtT y) { return mul_add(x, y, {b.zero(), b.zero()}); }
   ExtT sq(ExtT x) { return mul(x, x); }
@@ -61,8 +70,18 @@ struct Inner {                               // the circuit whose proofs are ver
       case QPGPU_GATE_CONSTANT: if (g.param != 2) return "inner Constant gate must hold 2 constants"; break;
       case QPGPU_GATE_BASESUM2: if (g.param != BASESUM_LIMBS) return "inner BaseSum gate must have 63 limbs"; break;
       case QPGPU_GATE_ARITHMETIC: if (g.param != ARITH_OPS) return "inner Arithmetic gate must hold 20 operations"; break;
-      default: return "the in-circuit verifier covers the leaf gate set only (gate tag " + std::to_string(g.tag) + ")";
+      case QPGPU_GATE_POSEIDON_MDS: break;
+      case QPGPU_GATE_ARITHMETIC_EXTENSION: if (g.param != ARITH_EXT_OPS) return "inner ArithmeticExtension gate must hold 10 operations"; break;
+      case QPGPU_GATE_REDUCING: if (g.param != REDUCING_COEFFS) return "inner Reducing gate must hold 43 coefficients"; break;
+      case QPGPU_GATE_REDUCING_EXTENSION: if (g.param != REDUCING_EXT_COEFFS) return "inner ReducingExtension gate must hold 32 coefficients"; break;
+      case QPGPU_GATE_RANDOM_ACCESS: if (g.param != RA_BITS || g.param2 != RA_COPIES || g.param3 != RA_EXTRA) return "inner RandomAccess gate must be (4 bits, 4 copies, 2 constants)"; break;
+      case QPGPU_GATE_COSET_INTERPOLATION:
+        if (g.param != COSET_BITS || g.param2 != COSET_DEG || g.table_len != COSET_NP || !g.table) return "inner CosetInterpolation gate must be (4 bits, degree 6)";
+        for (int i = 0; i < COSET_NP; i++) if (g.table[i] != Builder::coset_weights()[i]) return "inner CosetInterpolation gate: unexpected barycentric weights";
+        break;
+      default: return "the in-circuit verifier does not cover gate tag " + std::to_string(g.tag);
     }
+    for (auto& g : gates) g.table = nullptr;                     // the weights are Builder::coset_weights() (checked above)
     if (d.num_wires != W_ || d.num_routed != R_ || d.num_challenges != 2 || d.fri_rate_bits != 3 || d.quotient_degree_factor != 8 || d.num_gate_constraints != 123)
       return "inner circuit is not a standard_recursion_config circuit";
     if (d.fri_num_layers > 8 || d.degree_bits + d.fri_rate_bits > 28 || d.fri_cap_height > d.degree_bits) return "inner FRI shape out of range";
@@ -144,7 +163,8 @@ static std::vector<Target> indicators(Builder& b, const std::vector<BoolT>& bits
   return ind;
 }
 // Merkle opening: leaf digest up `sibs.size()` levels with the index bits choosing the side (Poseidon gate swap), root == cap[index >> depth]
-static void verify_merkle(Builder& b, const std::vector<Target>& leaf, const std::vector<Hash4>& sibs, const BoolT* bits, const std::vector<Hash4>& cap, const std::vector<Target>& cap_ind) {
+static void verify_merkle(Builder& b, const std::vector<Target>& leaf, const std::vector<Hash4>& sibs, const BoolT* bits, const std::vector<Hash4>& cap, const std::vector<Target>& cap_ind,
+                          const Target* cap_index = nullptr) {
   Hash4 cur = hash_or_noop(b, leaf);
   for (size_t l = 0; l < sibs.size(); l++) {
     Target st[12]; for (int i = 0; i < 4; i++) { st[i] = cur.e[i]; st[4 + i] = sibs[l].e[i]; st[8 + i] = b.zero(); }
@@ -152,6 +172,11 @@ static void verify_merkle(Builder& b, const std::vector<Target>& leaf, const std
     for (int i = 0; i < 4; i++) cur.e[i] = st[i];
   }
   for (int f = 0; f < 4; f++) {
+    if (cap_index && cap.size() <= (size_t)RA_VEC) {                          // one RandomAccess copy per digest element
+      std::vector<Target> list; for (const Hash4& h : cap) list.push_back(h.e[f]);
+      b.connect(b.random_access(*cap_index, list), cur.e[f]);
+      continue;
+    }
     Target sel = b.zero();
     for (size_t k = 0; k < cap.size(); k++) sel = b.mul_add(cap_ind[k], cap[k].e[f], sel);
     b.connect(sel, cur.e[f]);
@@ -162,6 +187,11 @@ static u64 rev_bits(u64 x, int bits) { u64 r = 0; for (int i = 0; i < bits; i++)
 static void mds_ext(G& g, ExtT st[12], const u64* next_rc) {                  // MDS layer, then the next round's constants (folded into the sums' start)
   static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   ExtT out[12];
+  if (g.rg) {                                                                // one PoseidonMds row, then twelve base additions
+    g.b.poseidon_mds(st, out);
+    for (int r = 0; r < 12; r++) st[r] = next_rc ? g.add_const(out[r], next_rc[r]) : out[r];
+    return;
+  }
   for (int r = 0; r < 12; r++) {
     ExtT acc = next_rc ? g.cst(next_rc[r]) : g.cst(0);
     for (int i = 0; i < 12; i++) acc = g.scale_add(st[(i + r) % 12], C[i], acc);
@@ -170,6 +200,14 @@ static void mds_ext(G& g, ExtT st[12], const u64* next_rc) {                  //
   }
   for (int r = 0; r < 12; r++) st[r] = out[r];
 }
+
+// E[X]/(X^2 - 7) over E = F_{p^2}: what a pair of extension-valued wires means at zeta (upstream's ExtensionAlgebra)
+struct AlgT { ExtT a, b; };
+static inline AlgT alg(const ExtT* w, int i) { return AlgT{w[i], w[i + 1]}; }
+static AlgT alg_add(G& g, AlgT x, AlgT y) { return AlgT{g.add(x.a, y.a), g.add(x.b, y.b)}; }
+static AlgT alg_sub(G& g, AlgT x, AlgT y) { return AlgT{g.sub(x.a, y.a), g.sub(x.b, y.b)}; }
+static AlgT alg_mul(G& g, AlgT x, AlgT y) { return AlgT{g.kmul_add(7, x.b, y.b, 1, g.mul(x.a, y.a)), g.mul_add(x.a, y.b, g.mul(x.b, y.a))}; }
+static AlgT alg_scale(G& g, AlgT x, ExtT s) { return AlgT{g.mul(x.a, s), g.mul(x.b, s)}; }
 
 // Gate constraints of the leaf gate set at zeta: terms[j] += filter_g * c_{g,j} (csrc/verify.hip eval_leaf_gate_constraints).
 static void eval_gate_constraints(G& g, const Inner& in, const ExtT* consts, const ExtT* wires, const Hash4& pi_hash, std::vector<ExtT>& terms) {
@@ -228,6 +266,71 @@ static void eval_gate_constraints(G& g, const Inner& in, const ExtT* consts, con
         for (int i = 0; i < 12; i++) put(k++, g.sub(st[i], wires[12 + i]));
         break;
       }
+      // ---- the recursive verifier's gates (formulas of oracle/gates.cc / csrc/verify.hip). A pair of wires opened at zeta is an element
+      // w0 + w1*X of the algebra E[X]/(X^2 - 7) over E = F_{p^2}.
+      case QPGPU_GATE_ARITHMETIC_EXTENSION:
+        for (int i = 0; i < (int)gt.param; i++) {
+          const AlgT r = alg_sub(g, alg(wires, 8 * i + 6), alg_add(g, alg_scale(g, alg_mul(g, alg(wires, 8 * i), alg(wires, 8 * i + 2)), consts[nsel]), alg_scale(g, alg(wires, 8 * i + 4), consts[nsel + 1])));
+          put(2 * i, r.a); put(2 * i + 1, r.b);
+        }
+        break;
+      case QPGPU_GATE_REDUCING: case QPGPU_GATE_REDUCING_EXTENSION: {
+        const bool xc = gt.tag == QPGPU_GATE_REDUCING_EXTENSION; const int nc = (int)gt.param, start_accs = 6 + (xc ? 2 : 1) * nc;
+        const AlgT alpha = alg(wires, 2); AlgT acc = alg(wires, 4);
+        for (int i = 0; i < nc; i++) {
+          const AlgT coeff = xc ? alg(wires, 6 + 2 * i) : AlgT{wires[6 + i], g.cst(0)};
+          const AlgT acc_i = i == nc - 1 ? alg(wires, 0) : alg(wires, start_accs + 2 * i);
+          const AlgT r = alg_sub(g, alg_add(g, alg_mul(g, acc, alpha), coeff), acc_i);
+          put(2 * i, r.a); put(2 * i + 1, r.b);
+          acc = acc_i;
+        }
+        break;
+      }
+      case QPGPU_GATE_RANDOM_ACCESS: {
+        const int bits = (int)gt.param, copies = (int)gt.param2, extra = (int)gt.param3, vec = 1 << bits, routed = (2 + vec) * copies + extra;
+        size_t k = 0;
+        for (int c = 0; c < copies; c++) {
+          const int base = (2 + vec) * c; const ExtT* bw = wires + routed + c * bits;
+          for (int i = 0; i < bits; i++) put(k++, g.mul(bw[i], g.sub(bw[i], g.cst(1))));
+          ExtT idx = g.cst(0); for (int i = bits - 1; i >= 0; i--) idx = g.scale_add(idx, 2, bw[i]);
+          put(k++, g.sub(idx, wires[base]));
+          std::vector<ExtT> list(wires + base + 2, wires + base + 2 + vec);
+          for (int i = 0, len = vec; i < bits; i++, len >>= 1) for (int j = 0; j < len / 2; j++) list[j] = g.mul_add(bw[i], g.sub(list[2 * j + 1], list[2 * j]), list[2 * j]);
+          put(k++, g.sub(list[0], wires[base + 1]));
+        }
+        for (int i = 0; i < extra; i++) put(k++, g.sub(consts[nsel + i], wires[(2 + vec) * copies + i]));
+        break;
+      }
+      case QPGPU_GATE_POSEIDON_MDS:
+        for (int h = 0; h < 2; h++) {                                            // the small-constant MDS acts on the two coordinates independently
+          ExtT st[12]; for (int i = 0; i < 12; i++) st[i] = wires[2 * i + h];
+          mds_ext(g, st, nullptr);
+          for (int i = 0; i < 12; i++) put(2 * i + h, g.sub(wires[24 + 2 * i + h], st[i]));
+        }
+        break;
+      case QPGPU_GATE_COSET_INTERPOLATION: {
+        const u64* dom = Builder::coset_domain(); const u64* wgt = Builder::coset_weights();
+        const AlgT x = alg(wires, COSET_S_SHIFTED);
+        size_t k = 0;
+        { const AlgT r = alg_sub(g, alg(wires, COSET_S_POINT), alg_scale(g, x, wires[0])); put(k++, r.a); put(k++, r.b); }
+        AlgT ev{g.cst(0), g.cst(0)}, pr{g.cst(1), g.cst(0)};
+        int lo = 0, hi = COSET_DEG;
+        for (int seg = 0; seg <= COSET_NI; seg++) {
+          for (int i = lo; i < hi; i++) {
+            const AlgT term{g.sub(x.a, g.cst(dom[i])), x.b};
+            const AlgT val{g.scale(wires[1 + 2 * i], wgt[i]), g.scale(wires[2 + 2 * i], wgt[i])};
+            ev = alg_add(g, alg_mul(g, ev, term), alg_mul(g, val, pr)); pr = alg_mul(g, pr, term);
+          }
+          if (seg == COSET_NI) break;
+          const AlgT iev = alg(wires, COSET_S_INTER + 2 * seg), ipr = alg(wires, COSET_S_INTER + 2 * (COSET_NI + seg));
+          { const AlgT r = alg_sub(g, iev, ev); put(k++, r.a); put(k++, r.b); }
+          { const AlgT r = alg_sub(g, ipr, pr); put(k++, r.a); put(k++, r.b); }
+          ev = iev; pr = ipr;
+          lo = 1 + (COSET_DEG - 1) * (seg + 1); hi = lo + COSET_DEG - 1 < COSET_NP ? lo + COSET_DEG - 1 : COSET_NP;
+        }
+        { const AlgT r = alg_sub(g, alg(wires, COSET_S_VALUE), ev); put(k++, r.a); put(k++, r.b); }
+        break;
+      }
       default: break;
     }
   }
@@ -235,8 +338,8 @@ static void eval_gate_constraints(G& g, const Inner& in, const ExtT* consts, con
 }
 
 // builder.verify_proof: every check of csrc/verify.hip's verify_host + the Merkle openings, as constraints.
-void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierDataT& vd) {
-  G g{b};
+void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierDataT& vd, bool rg) {
+  G g{b, rg};
   const int nch = in.nch; const size_t n = size_t(1) << in.log_n;
   static const bool report = getenv("QPC_TIMING") != nullptr; size_t rows_mark = b.num_rows_so_far();
   auto section = [&](const char* what) { if (report) { const size_t r = b.num_rows_so_far(); fprintf(stderr, "  verify_proof %-22s %6zu rows\n", what, r - rows_mark); rows_mark = r; } };
@@ -307,7 +410,9 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
     }
     terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
     for (int c = 0; c < nch; c++) {
-      ExtT van = g.cst(0); for (size_t i = terms.size(); i-- > 0;) van = g.mul_base_add(van, alphas[c], terms[i]);
+      ExtT van = g.cst(0);
+      if (rg) van = b.reduce_ext(g.base(alphas[c]), std::vector<ExtT>(terms.rbegin(), terms.rend()));      // sum_i terms[i] alpha^i on ReducingExtension rows
+      else for (size_t i = terms.size(); i-- > 0;) van = g.mul_base_add(van, alphas[c], terms[i]);
       ExtT qv = g.cst(0); for (int m = deg; m-- > 0;) qv = g.mul_add(qv, zeta_n, o_q[(size_t)c * deg + m]);
       g.assert_eq(van, g.mul(zh, qv));
     }
@@ -315,9 +420,13 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
   section("vanishing identity");
   // ---- FRI: reduced openings, then per query the initial combination, the layer folds, the final polynomial and every Merkle opening
   const size_t n0 = (size_t)in.S + in.W + in.Zp + in.Q;
-  std::vector<ExtT> apow(n0 + 1); apow[0] = g.cst(1); for (size_t i = 1; i <= n0; i++) apow[i] = g.mul(apow[i - 1], fri_alpha);
+  std::vector<ExtT> apow((rg ? (size_t)nch : n0) + 1); apow[0] = g.cst(1); for (size_t i = 1; i < apow.size(); i++) apow[i] = g.mul(apow[i - 1], fri_alpha);
   ExtT y0 = g.cst(0), y1 = g.cst(0);
-  { size_t j = 0;
+  if (rg) {                                                                      // sum_j op_j alpha^j: Horner from the last opening down, on ReducingExtension rows
+    std::vector<ExtT> ops(pf.op.begin(), pf.op.begin() + a_ext); ops.insert(ops.end(), pf.op.begin() + a_ext + nch, pf.op.end());
+    y0 = b.reduce_ext(fri_alpha, std::vector<ExtT>(ops.rbegin(), ops.rend()));
+    for (int i = 0; i < nch; i++) y1 = g.mul_add(o_zs_next[i], apow[i], y1);
+  } else { size_t j = 0;
     for (size_t i = 0; i < a_ext; i++, j++) y0 = g.mul_add(pf.op[i], apow[j], y0);
     for (size_t i = a_ext + nch; i < nop; i++, j++) y0 = g.mul_add(pf.op[i], apow[j], y0);
     for (int i = 0; i < nch; i++) y1 = g.mul_add(o_zs_next[i], apow[i], y1); }
@@ -331,14 +440,23 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
   for (uint32_t qi = 0; qi < in.d.fri_num_queries; qi++) {
     b.begin_segment(2);
     const QueryT& q = pf.q[qi]; const std::vector<BoolT>& bits = index_bits[qi];
-    const std::vector<Target> cap_ind = indicators(b, std::vector<BoolT>(bits.begin() + path, bits.end()));     // cap entry = index >> path (every tree of the query)
+    // cap entry = index >> path (every tree of the query): indicator sums, or RandomAccess rows fed with the index itself
+    const std::vector<BoolT> cap_bits(bits.begin() + path, bits.end());
+    std::vector<Target> cap_ind; Target cap_idx = b.zero();
+    const bool cap_ra = rg && cap_bits.size() <= (size_t)RA_BITS;
+    if (cap_ra) { for (size_t i = cap_bits.size(); i-- > 0;) cap_idx = b.arithmetic(2, 1, cap_idx, b.one(), cap_bits[i].t); }
+    else cap_ind = indicators(b, cap_bits);
+    const Target* cap_sel = cap_ra ? &cap_idx : nullptr;
     ExtT sum0 = g.cst(0), sum1 = g.cst(0); size_t j = 0;
+    std::vector<Target> row_values;                                               // the 255 unsalted values of the four rows, oracle by oracle
     for (int t = 0; t < 4; t++) {
       const std::vector<Hash4>& cap = t == 0 ? vd.cap : pf.caps[t - 1];
-      verify_merkle(b, q.row[t], q.sibs[t], bits.data(), cap, cap_ind);
-      for (size_t k = 0; k < unsalted[t]; k++, j++) sum0 = g.mul_base_add(apow[j], q.row[t][k], sum0);
+      verify_merkle(b, q.row[t], q.sibs[t], bits.data(), cap, cap_ind, cap_sel);
+      if (rg) row_values.insert(row_values.end(), q.row[t].begin(), q.row[t].begin() + unsalted[t]);
+      else for (size_t k = 0; k < unsalted[t]; k++, j++) sum0 = g.mul_base_add(apow[j], q.row[t][k], sum0);
       if (t == 2) for (int k = 0; k < nch; k++) sum1 = g.mul_base_add(apow[k], q.row[t][k], sum1);
     }
+    if (rg) sum0 = b.reduce_base(fri_alpha, std::vector<Target>(row_values.rbegin(), row_values.rend()));   // sum_j row_j alpha^j on Reducing rows
     // the point: g * w_N^rev(index)
     Target sx = b.constant(GL_GEN);
     for (int i = 0; i < in.log_N; i++) sx = b.mul(sx, b.mul_add(bits[i].t, b.constant(gl_sub(gl_pow(wN, u64(1) << (in.log_N - 1 - i)), 1)), b.one()));
@@ -349,8 +467,12 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
       const int ab = in.arity[l], m = 1 << ab;
       const std::vector<BoolT> within(bits.begin() + used, bits.begin() + used + ab);
       { std::vector<Target> leaf; for (const ExtT& e : q.evals[l]) { leaf.push_back(e.a); leaf.push_back(e.b); }
-        verify_merkle(b, leaf, q.lsibs[l], bits.data() + used + ab, pf.fri_caps[l], cap_ind); }
-      { const std::vector<Target> ind = indicators(b, within);                   // evals[within] == the value carried from the layer below
+        verify_merkle(b, leaf, q.lsibs[l], bits.data() + used + ab, pf.fri_caps[l], cap_ind, cap_sel); }
+      if (rg) {                                                                  // evals[within] == the value carried from the layer below (two RandomAccess copies)
+        Target widx = b.zero(); for (int i = ab; i-- > 0;) widx = b.arithmetic(2, 1, widx, b.one(), within[i].t);
+        std::vector<Target> la, lb; for (int k = 0; k < m; k++) { la.push_back(q.evals[l][k].a); lb.push_back(q.evals[l][k].b); }
+        g.assert_eq(ExtT{b.random_access(widx, la), b.random_access(widx, lb)}, old_eval);
+      } else { const std::vector<Target> ind = indicators(b, within);
         ExtT sel = g.cst(0); for (int k = 0; k < m; k++) sel = g.mul_base_add(q.evals[l][k], ind[k], sel);
         g.assert_eq(sel, old_eval); }
       // interpolate the coset {c0 g^i} -> evals[rev(i)] at beta (barycentric): P(beta) = (beta^m - c0^m) / (m c0^m) * sum_i y_i x_i / (beta - x_i)
@@ -358,6 +480,13 @@ void verify_proof(Builder& b, const Inner& in, const ProofT& pf, const VerifierD
       Target c0 = sx;                                                            // sx * g^(-rev(within))
       for (int i = 0; i < ab; i++) c0 = b.mul(c0, b.mul_add(within[i].t, b.constant(gl_sub(gl_pow(gm, (u64)m - (u64(1) << (ab - 1 - i))), 1)), b.one()));
       const ExtT beta = fri_betas[l];
+      if (rg && ab == COSET_BITS) {                                              // one CosetInterpolation row: the polynomial through (c0 g^i, evals[rev(i)]) at beta
+        ExtT vals[COSET_NP]; for (int i = 0; i < m; i++) vals[i] = q.evals[l][rev_bits((u64)i, ab)];
+        old_eval = b.coset_interpolate(c0, vals, beta);
+        for (int i = 0; i < ab; i++) sx = b.mul(sx, sx);
+        used += ab; lg -= ab;
+        continue;
+      }
       ExtT acc = g.cst(0);
       for (int i = 0; i < m; i++) {
         const Target xi = b.mul(c0, b.constant(gl_pow(gm, (u64)i)));
@@ -411,7 +540,7 @@ extern "C" int qpc_aggregation_circuit_build_ex(const qpgpu_circuit_desc* inner_
     const VerifierDataT vd = add_verifier_data_targets(b, info->inner);         // tree.rs:113-114
     for (uint32_t i = 0; i < num_proofs; i++) {                                 // tree.rs:117-126
       const ProofT pt = add_proof_targets(b, info->inner);
-      verify_proof(b, info->inner, pt, vd);
+      verify_proof(b, info->inner, pt, vd, getenv("QPC_NODE_LEAF_GATES") == nullptr);
       for (Target t : pt.pis) b.register_public_input(t);
     }
     b.build();
