@@ -433,6 +433,50 @@ def main():
                 tree["leaf_batch_verify"] = {"error": repr(e)[:160]}
             to_check += [("tree_leaf_first", leaf_proofs[0], 0, seeds[0]), ("tree_leaf_last", leaf_proofs[-1], (leaves_per_rank - 1) % nwit, seeds[0] + leaves_per_rank - 1)]
             tree_leaves, tree_root, tree_desc_owner = leaf_proofs, root_bytes, root_cd
+            # The same leaves under a wide tree, TreeAggregationConfig(8, d): 64 leaves per rank are 8 level-0 nodes and one level-1 node, all local;
+            # with 8 ranks one more level follows, fed by the single gather of the path (8 node proofs). Fewer, larger nodes: the blinding rows and
+            # the power-of-two padding are paid per node, so 73 nodes of 2^16 rows cost a third of 511 nodes of 2^15.
+            n_total = leaves_per_rank * world
+            wide_depth = int(round(np.log(n_total) / np.log(8)))
+            if 8 ** wide_depth == n_total:
+                try:
+                    cfg8 = agg.TreeAggregationConfig(8, wide_depth)
+                    np8 = agg.RecursiveChunkProver(LeafData(), device=local_rank)
+                    ok8 = 1
+                    try:
+                        t_b8 = time.perf_counter()
+                        warm = list(leaf_proofs[:8])
+                        for lvl in range(wide_depth):
+                            warm = [np8(warm, lvl).proof.to_bytes()] * 8
+                        t_b8 = time.perf_counter() - t_b8
+                        agg.aggregate_to_tree(leaf_proofs, agg.TreeAggregationConfig(8, 2), np8)          # untimed: workspaces of the two local levels
+                    except Exception:
+                        ok8 = 0
+                    if dist is not None:
+                        t = torch.tensor([ok8], dtype=torch.int32, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok8 = int(t.item())
+                    if ok8:
+                        barrier(); t6 = time.perf_counter()
+                        if dist is not None:
+                            root8 = agg.aggregate_to_tree_distributed(leaf_proofs, cfg8, np8, lambda lvl: np8.proof_size_of_level(lvl, 8), device=(dev if backend == "nccl" else None))
+                        else:
+                            root8 = agg.aggregate_to_tree(leaf_proofs, cfg8, np8)
+                        barrier(); t8 = time.perf_counter() - t6
+                        if dist is not None:
+                            t = torch.tensor([t8], dtype=torch.float64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MAX); t8 = float(t.item())
+                        cd8 = np8.level(wide_depth - 1, 8)[0]
+                        rb8 = root8.proof.to_bytes() if hasattr(root8.proof, "to_bytes") else bytes(root8.proof)
+                        wide = {"branching": 8, "levels": wide_depth, "nodes": sum(8 ** k for k in range(wide_depth)), "tree_stage_s": round(t8, 4),
+                                "total_s": round(tl + t8, 4), "node_circuit_rows": cd8._built.row_counts()["rows_in_use"], "node_circuit_degree_bits": int(cd8.desc.degree_bits),
+                                "node_circuits_build_s": round(t_b8, 2), "root_bytes": len(rb8)}
+                        if rank == 0:
+                            v8 = H.GpuVerifier(cd8.desc, cd8.constants_sigmas_cap(), device=local_rank)
+                            wide["root_verified"] = bool(v8.verify(rb8) is None); v8.close()
+                            pis8 = [int(x) for x in np.frombuffer(rb8[-8 * cd8.num_public_inputs:], dtype="<u8")]
+                            wide["root_public_inputs_are_the_leaves"] = bool(pis8[:len(mine)] == mine and len(pis8) == len(mine) * world)
+                        tree["wide_tree"] = wide
+                    np8.close()
+                except Exception as e:
+                    tree["wide_tree"] = {"error": repr(e)[:200]}
         except Exception as e:                                  # never let the extra measurement take the headline down
             tree = {"error": repr(e)[:300]}
 

@@ -373,16 +373,26 @@ std::string Builder::generate(const u64* inputs, const uint8_t* blinding_key, u6
 
   bg.join();                                                          // the matrix is zeroed (and its blinding rows written)
   lap("join");
+  // the fill: routed (and special-row) cells from their classes, then the Poseidon rows' other wires — column ranges, so that with
+  // several threads each writes its own part of the matrix (fill_dst_ is in column-major order)
   { const size_t m = fill_dst_.size(); const uint32_t* fd = fill_dst_.data(); const uint32_t* fc = fill_cls_.data(); const u64* vp = val.data();
-    for (size_t i = 0; i < m; i++) { if (i + 24 < m) __builtin_prefetch(vp + fc[i + 24]); const u64 v = vp[fc[i]]; wires[fd[i]] = v == UNSET ? 0 : v; } }      // classes never set hold 0
-  { const size_t np = ptrace.size() / 108;                             // non-routed wires of the Poseidon rows, column by column (sequential writes):
-    for (size_t r = 0; r < np; r++) if (ptrace[r * 108 + 1]) {         // delta = swap * (in[i+4] - in[i]),
-      const size_t row = (size_t)ptrace[r * 108];
+    const size_t np = ptrace.size() / 108; const u64* pt = ptrace.data();
+    auto fill_cells = [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) { if (i + 24 < hi) __builtin_prefetch(vp + fc[i + 24]); const u64 v = vp[fc[i]]; wires[fd[i]] = v == UNSET ? 0 : v; }      // classes never set hold 0
+    };
+    auto fill_sbox = [&](int c_lo, int c_hi) {                         // the S-box inputs, column by column (sequential writes)
+      for (int i = c_lo; i < c_hi; i++) { u64* col = wires + (size_t)(29 + i) * n; for (size_t r = 0; r < np; r++) col[(size_t)pt[r * 108]] = pt[r * 108 + 2 + i]; }
+    };
+    const int ft = threads > 1 ? std::min(threads, 8) : 1;
+    if (ft > 1 && m > 65536) {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < ft; t++) pool.emplace_back([&, t] { fill_cells(m * t / ft, m * (t + 1) / ft); fill_sbox(106 * t / ft, 106 * (t + 1) / ft); });
+      fill_cells(0, m / ft); fill_sbox(0, 106 / ft);
+      for (auto& th : pool) th.join();
+    } else { fill_cells(0, m); fill_sbox(0, 106); }
+    for (size_t r = 0; r < np; r++) if (pt[r * 108 + 1]) {             // delta = swap * (in[i+4] - in[i]) (after the routed cells are in place)
+      const size_t row = (size_t)pt[r * 108];
       for (int i = 0; i < 4; i++) wires[(size_t)(25 + i) * n + row] = gl_sub(wires[(size_t)(4 + i) * n + row], wires[(size_t)i * n + row]);
-    }
-    for (int i = 0; i < 106; i++) {                                    // the S-box inputs
-      u64* col = wires + (size_t)(29 + i) * n;
-      for (size_t r = 0; r < np; r++) col[(size_t)ptrace[r * 108]] = ptrace[r * 108 + 2 + i];
     } }
   lap("fill");
   return "";

@@ -336,16 +336,18 @@ __global__ void __launch_bounds__(16 * G) k_levels_coop_fused(const u64* __restr
     o += par * 4; par >>= 1;
   }
 }
-static constexpr size_t COOP_MAX_PARENTS = 16384;
+static constexpr size_t COOP_MAX_PARENTS = 16384, COOP_MAX_PARENTS_BATCH = 4096;
 void merkle_levels(u64* levels, size_t num_leaves, int cap_height, hipStream_t s, int levels_done, bool batch) {
   // The 2-lane form for 32 K / 64 K parents, the 16-lane form from 16 K parents down (lowest latency) — in batches too: the
   // 16-lane form costs 2.8x and the 2-lane form 1.4x the instructions of one permutation per lane (tools/valu_budget.py) and
   // batches are VALU-bound, yet per-lane levels down to 4 K parents measured 341-344 vs 356-369 proofs/s (medians of 9 batches
   // of 48, four worker streams): the longer critical path of every proof costs more overlap than the saved instructions buy.
-  (void)batch;
+  // With eight worker streams (round 3) the device is fuller and the switch to the 16-lane form moves down: in batches the 2-lane form
+  // also takes the 8 K and 16 K-parent levels (QPGPU_COOP_MAX sweep, medians of 4 x 6 batches of 64: 16384 -> 415, 8192 -> 421, 4096 -> 424,
+  // 2048 -> 425, 1024 -> 420, 256 -> 416 proofs/s; profiles/r03_batch_levels_ab.txt). A single proof keeps 16384.
   const int env_pair = opts().pair_max, env_coop = opts().coop_max;   // tuning overrides
   const size_t pair_max = env_pair >= 0 ? (size_t)env_pair : PAIR_MAX_LEAVES;
-  const size_t coop_max = env_coop >= 0 ? (size_t)env_coop : COOP_MAX_PARENTS;
+  const size_t coop_max = env_coop >= 0 ? (size_t)env_coop : (batch ? COOP_MAX_PARENTS_BATCH : COOP_MAX_PARENTS);
   size_t cnt = num_leaves, cap = size_t(1) << cap_height; u64* cur = levels;
   for (int l = 0; l < levels_done; l++) { cur += cnt * 4; cnt >>= 1; }
   while (cnt > cap) {

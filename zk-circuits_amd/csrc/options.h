@@ -18,7 +18,7 @@ struct Options {
   int l0_table = 1;           // QPGPU_L0_TABLE=0: recompute L_0(x) per point instead of the per-circuit table
   int pair_leaves = 0;        // QPGPU_PAIR_LEAVES=1: 2-lane pair form for leaf hashing of small trees
   int pair_max = -1;          // QPGPU_PAIR_MAX: largest level (parents) hashed in the pair form (-1: 2^18)
-  int coop_max = -1;          // QPGPU_COOP_MAX: largest level (parents) hashed in the 16-lane form (-1: 16384)
+  int coop_max = -1;          // QPGPU_COOP_MAX: largest level (parents) hashed in the 16-lane form (-1: 16384 for a single proof, 4096 inside qpgpu_prove_batch)
   int fuse_levels = 1;        // QPGPU_FUSE_LEVELS=0: one launch per latency-bound tree level
   int ntt16 = 1;              // QPGPU_NTT16: 0 off, 1 sizes <= 2^12, 2 every supported size
   int ntt_strided = 1;        // QPGPU_NTT_STRIDED=0: tiled multi-pass NTT only
