@@ -112,7 +112,8 @@ void l0_table(const CircuitDev& cd, u64* out, const NttPlan& pl, hipStream_t s);
 void alpha_powers(u64* out, Chal2 alphas, int nch, int count, hipStream_t s);
 // Quotient values (row a8) on the LDE coset in leaf order: out [nch][N]. cs_lde [S][N], wires_lde [.][N] (stride N), zs_lde [.][N].
 void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
-                   const u64* alpha_pows, int ap_stride, const u64* pi_hash /*host values*/, u64* out, const NttPlan& pl, hipStream_t s);
+                   const u64* alpha_pows, int ap_stride, const u64* pi_hash /*host values*/, u64* out, const NttPlan& pl, hipStream_t s, bool leaf_gate_set = false);
+bool quotient_leaf_set(const CircuitDev& cd);       // the circuit's gates are exactly the leaf set with standard parameters (shared-load form of the fused kernel)
 
 // The fused kernel's two independent halves (part 1: L_0 + permutation terms, part 2: gate constraints) as separate launches
 // writing raw sums [nch][N]; quotient_sum adds them and divides by Z_H. Used to run both halves concurrently on two streams.

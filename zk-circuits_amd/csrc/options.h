@@ -26,6 +26,7 @@ struct Options {
   int verify_coop_max = 16384; // QPGPU_VERIFY_COOP_MAX: most Merkle openings per launch checked in the 16-lane form (0: always one lane per opening)
   int poseidon_fast = -1;     // QPGPU_POSEIDON_FAST: form of the permutation's partial rounds in the leaf-hash kernels: -1 auto (fast where the chip is
                               //   full: trees of >= 2^17 leaves and batches), 0 literal everywhere, 1 fast everywhere (same digests either way)
+  int quotient_shared_loads = 1; // QPGPU_QUOTIENT_SHARED_LOADS=0: the fused quotient kernel loads every gate's wires on its own also for the leaf gate set
   int pow_first_shift = 0;    // QPGPU_POW_FIRST_SHIFT: the first proof-of-work launch tests 2^(pow_bits + shift) candidates (same proof bytes: the smallest witness wins)
 };
 const Options& opts();

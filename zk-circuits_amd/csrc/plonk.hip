@@ -162,7 +162,10 @@ struct Zh8 { u64 zh[8]; u64 zh_inv[8]; };
 // PART 0: everything, output = vanishing / Z_H. PART 1: L_0 and permutation terms only, PART 2: gate constraints only; both write
 // their raw alpha-weighted sums to `out` ([nch][N]); k_quotient_sum adds the two and divides by Z_H. The halves are independent,
 // so a single proof runs them on two streams at once (each alone is only 2 waves/SIMD and stalls on its ~200-450 loads per point).
-template <int PART>
+// LS (leaf gate set, PART 0): the circuit's gates are exactly Noop / Constant{2} / PublicInput / BaseSum{63} / Arithmetic{20} / Poseidon with
+// 80 routed wires in chunks of 8. The four cheap gates then take their wires from the permutation argument's chunk loads (each of wires
+// 0..79 is loaded once for both) instead of loading them again gate by gate: 323 column loads per point instead of 473 (241 algorithmic).
+template <int PART, bool LS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_quotient(CircuitDev cd, const u64* __restrict__ cs, const u64* __restrict__ wl,
                                                   const u64* __restrict__ zl, Chal2 betas, Chal2 gammas,
                                                   const u64* __restrict__ apw, int ap_stride, Pi4 pih, Zh8 zh, u64 n_inv,
@@ -188,6 +191,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       tot0 = gl_add(tot0, gl_mul(t, ap0[term])); tot1 = gl_add(tot1, gl_mul(t, ap1[term])); term++;
     }
   }
+  // ---- LS: filters of the four cheap gates, their accumulators (alpha powers of the gate section start behind the permutation terms)
+  const int nsel_ = cd.num_selectors;
+  u64 f_cst = 0, f_pi = 0, f_bs = 0, f_ar = 0, ls_lc0 = 0, ls_lc1 = 0, bs_w0 = 0, bs_sum = 0;
+  Acc192 m0{0, 0, 0}, m1{0, 0, 0}, b0{0, 0, 0}, b1{0, 0, 0}, a0{0, 0, 0}, a1{0, 0, 0};      // misc (Constant, PublicInput: filter folded in), BaseSum, Arithmetic
+  const u64* gp0 = ap0 + (nch + nch * (npp + 1)); const u64* gp1 = ap1 + (nch + nch * (npp + 1));
+  if (LS && PART == 0) {
+    ls_lc0 = cs[(size_t)nsel_ * N + L]; ls_lc1 = cs[(size_t)(nsel_ + 1) * N + L];
+    for (int gi = 0; gi < cd.num_gates; gi++) {
+      const GateDev g = cd.gates[gi];
+      if (g.tag == QPGPU_GATE_NOOP || g.tag == QPGPU_GATE_POSEIDON) continue;
+      const u64 sv = cs[(size_t)g.sel_index * N + L];
+      u64 filter = 1;
+      for (u32 i = g.grp_lo; i < g.grp_hi; i++) if ((int)i != gi) filter = gl_mul(filter, gl_sub((u64)i, sv));
+      if (nsel_ > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, sv));
+      if (g.tag == QPGPU_GATE_CONSTANT) f_cst = filter; else if (g.tag == QPGPU_GATE_PUBLIC_INPUT) f_pi = filter;
+      else if (g.tag == QPGPU_GATE_BASESUM2) f_bs = filter; else f_ar = filter;
+    }
+  }
   // ---- permutation checks: both challenges share the loads of w_j / sigma_j; factors and running products are lazy residues,
   // the alpha-weighted terms go into one 192-bit accumulator per challenge
   if (PART != 2) {
@@ -210,6 +231,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
           de[c] = mul_lazy(de[c], add_lazy_canon(add_lazy_canon(mul_lazy(betas.v[c], sg), w), gammas.v[c]));
         }
       }
+      if (LS && PART == 0) {                               // the cheap gates on the chunk's wires 8k .. 8k+7
+        if (k == 0) {
+          for (int i = 0; i < 2; i++) { const u64 t = gl_mul(f_cst, gl_sub(i == 0 ? ls_lc0 : ls_lc1, wv[i])); acc_mul(m0, t, gp0[i]); acc_mul(m1, t, gp1[i]); }
+          for (int i = 0; i < 4; i++) { const u64 t = gl_mul(f_pi, gl_sub(wv[i], pih.v[i])); acc_mul(m0, t, gp0[i]); acc_mul(m1, t, gp1[i]); }
+          bs_w0 = wv[0];
+        }
+        if (k < 8) {                                       // BaseSum: limb l sits on wire 1 + l; constraint 1 + l = limb (limb - 1); sum of limb 2^l against wire 0
+          u64 local = 0;
+#pragma unroll
+          for (int u = 7; u >= 0; u--) {
+            if (k == 0 && u == 0) continue;
+            const u64 b = wv[u];
+            local = gl_add(gl_add(local, local), b);
+            const u64 t = gl_mul(b, gl_sub(b, 1)); const int idx = 8 * k + u;
+            acc_mul(b0, t, gp0[idx]); acc_mul(b1, t, gp1[idx]);
+          }
+          bs_sum = gl_add(bs_sum, gl_mul(local, k == 0 ? 1 : (u64(1) << (8 * k - 1))));      // chunk 0's Horner already starts at limb 0 (wire 1)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {                      // Arithmetic: operations 2k, 2k + 1
+          const u64 t = gl_sub(wv[4 * u + 3], gl_add(gl_mul(ls_lc0, gl_mul(wv[4 * u], wv[4 * u + 1])), gl_mul(ls_lc1, wv[4 * u + 2])));
+          acc_mul(a0, t, gp0[2 * k + u]); acc_mul(a1, t, gp1[2 * k + u]);
+        }
+      }
       for (int c = 0; c < nch; c++) {
         const u64 next = k < npp ? zl[(size_t)(nch + c * npp + k) * N + L] : zl[(size_t)c * N + Ln];
         const u64 t = sub_lazy_canon(mul_lazy(prev[c], nu[c]), canon(mul_lazy(next, de[c])));
@@ -220,6 +265,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     tot0 = gl_add(tot0, acc_reduce(pa[0]));
     if (nch > 1) tot1 = gl_add(tot1, acc_reduce(pa[1]));
+    if (LS && PART == 0) {
+      { const u64 t = gl_sub(bs_sum, bs_w0); acc_mul(b0, t, gp0[0]); acc_mul(b1, t, gp1[0]); }
+      tot0 = gl_add(tot0, gl_add(acc_reduce(m0), gl_add(gl_mul(f_bs, acc_reduce(b0)), gl_mul(f_ar, acc_reduce(a0)))));
+      if (nch > 1) tot1 = gl_add(tot1, gl_add(acc_reduce(m1), gl_add(gl_mul(f_bs, acc_reduce(b1)), gl_mul(f_ar, acc_reduce(a1)))));
+    }
   }
   term = nch + nch * (npp + 1);
   // ---- gate constraints: sum_g filter_g * sum_j alpha^(term+j) c_{g,j}
@@ -228,6 +278,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const u64 lc0 = cs[(size_t)nsel * N + L], lc1 = cs[(size_t)(nsel + 1) * N + L];
   for (int gi = 0; PART != 1 && gi < cd.num_gates; gi++) {
     const GateDev g = cd.gates[gi];
+    if (LS && PART == 0 && g.tag != QPGPU_GATE_POSEIDON) continue;       // done above, on the permutation argument's loads
     const u64 sv = cs[(size_t)g.sel_index * N + L];
     u64 filter = 1;
     for (u32 i = g.grp_lo; i < g.grp_hi; i++) if ((int)i != gi) filter = gl_mul(filter, gl_sub((u64)i, sv));
@@ -494,21 +545,44 @@ void quotient_eval_part(int part, const CircuitDev& cd, const u64* cs_lde, const
   Pi4 pih; for (int i = 0; i < 4; i++) pih.v[i] = pi_hash[i];
   const Zh8 zh = quotient_zh(cd);
   dim3 grid((unsigned)((N + 255) / 256));
-  if (part == 1) hipLaunchKernelGGL(k_quotient<1>, grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
-  else hipLaunchKernelGGL(k_quotient<2>, grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
+  if (part == 1) hipLaunchKernelGGL((k_quotient<1, false>), grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
+  else hipLaunchKernelGGL((k_quotient<2, false>), grid, dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas, alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out_part, pl.rt, pl.log_M);
 }
 void quotient_sum(const CircuitDev& cd, const u64* a, const u64* b, u64* out, hipStream_t s) {
   const int log_N = cd.log_n + cd.rate_bits; const size_t N = size_t(1) << log_N;
   hipLaunchKernelGGL(k_quotient_sum, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, log_N, cd.rate_bits, cd.num_challenges, a, b, quotient_zh(cd), out);
 }
+// The shapes k_quotient<0, true> is written for: each of the six leaf gates at most once with the standard parameters, 80 routed wires in
+// ten chunks of 8 (quotient degree factor 8, nine partial products), Poseidon present.
+bool quotient_leaf_set(const CircuitDev& cd) {
+  if (cd.num_routed != 80 || cd.qdf != 8 || cd.num_pp != 9 || cd.num_challenges > 2 || cd.num_gate_constraints != 123) return false;
+  int seen[16] = {0}; bool poseidon = false;
+  for (int i = 0; i < cd.num_gates; i++) {
+    const GateDev& g = cd.gates[i];
+    if (g.tag >= 16 || seen[g.tag]++) return false;
+    switch (g.tag) {
+      case QPGPU_GATE_NOOP: case QPGPU_GATE_PUBLIC_INPUT: break;
+      case QPGPU_GATE_POSEIDON: poseidon = true; break;
+      case QPGPU_GATE_CONSTANT: if (g.param != 2) return false; break;
+      case QPGPU_GATE_BASESUM2: if (g.param != 63) return false; break;
+      case QPGPU_GATE_ARITHMETIC: if (g.param != 20) return false; break;
+      default: return false;
+    }
+  }
+  return poseidon;
+}
 void quotient_eval(const CircuitDev& cd, const u64* cs_lde, const u64* wires_lde, const u64* zs_lde, Chal2 betas, Chal2 gammas,
-                   const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out, const NttPlan& pl, hipStream_t s) {
+                   const u64* alpha_pows, int ap_stride, const u64* pi_hash, u64* out, const NttPlan& pl, hipStream_t s, bool leaf_gate_set) {
   const int log_N = cd.log_n + cd.rate_bits; const size_t n = size_t(1) << cd.log_n, N = size_t(1) << log_N;
   Pi4 pih; for (int i = 0; i < 4; i++) pih.v[i] = pi_hash[i];
   Zh8 zh; u64 gn = gl_pow(GL_GEN, n), w = gl_root(cd.rate_bits), t = 1;
   for (int k = 0; k < (1 << cd.rate_bits) && k < 8; k++) { zh.zh[k] = gl_sub(gl_mul(gn, t), 1); zh.zh_inv[k] = gl_inv(zh.zh[k]); t = gl_mul(t, w); }
-  hipLaunchKernelGGL(k_quotient<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
-                     alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out, pl.rt, pl.log_M);
+  if (leaf_gate_set)
+    hipLaunchKernelGGL((k_quotient<0, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
+                       alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out, pl.rt, pl.log_M);
+  else
+    hipLaunchKernelGGL((k_quotient<0, false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cd, cs_lde, wires_lde, zs_lde, betas, gammas,
+                       alpha_pows, ap_stride, pih, zh, gl_inv((u64)n), out, pl.rt, pl.log_M);
 }
 
 // ------------------------------------------------------------------ openings

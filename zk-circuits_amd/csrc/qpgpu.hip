@@ -53,6 +53,7 @@ void options_refresh_from_env() {
   o.pair_leaves = geti("QPGPU_PAIR_LEAVES", o.pair_leaves); o.pair_max = geti("QPGPU_PAIR_MAX", o.pair_max); o.coop_max = geti("QPGPU_COOP_MAX", o.coop_max);
   o.fuse_levels = geti("QPGPU_FUSE_LEVELS", o.fuse_levels); o.ntt16 = geti("QPGPU_NTT16", o.ntt16); o.ntt_strided = geti("QPGPU_NTT_STRIDED", o.ntt_strided);
   o.ntt_m8 = geti("QPGPU_NTT_M8", o.ntt_m8);
+  o.quotient_shared_loads = geti("QPGPU_QUOTIENT_SHARED_LOADS", o.quotient_shared_loads);
   o.pow_first_shift = geti("QPGPU_POW_FIRST_SHIFT", o.pow_first_shift); o.poseidon_fast = geti("QPGPU_POSEIDON_FAST", o.poseidon_fast);
   o.verify_coop_max = geti("QPGPU_VERIFY_COOP_MAX", o.verify_coop_max);
   const Options* cur = g_opts_cur.load(std::memory_order_relaxed);
@@ -115,7 +116,7 @@ struct qpgpu_circuit {
   u64* d_fri_scale[MAX_FRI_LAYERS + 1] = {nullptr};
   u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_dig = nullptr;
   std::vector<u64> cs_cap;
-  bool split_quotient = false, leaf_gates_only = true;
+  bool split_quotient = false, leaf_gates_only = true, quotient_ls = false;
   Layout lay; size_t ws_bytes = 0;
   std::mutex mu; std::vector<Workspace*> free_ws;
 };
@@ -493,6 +494,7 @@ int qpgpu_circuit_create(qpgpu_ctx* ctx, const qpgpu_circuit_desc* desc, qpgpu_c
   CC_TRY(hipGetLastError());
   { size_t cap_off = merkle_total_digests(N, c->cap_h) - capn; CC_TRY(hipMemcpy(c->cs_cap.data(), c->d_cs_dig + cap_off * 4, capn * 32, hipMemcpyDeviceToHost)); }
   c->split_quotient = quotient_split_supported(c->cd) && c->leaf_gates_only;
+  c->quotient_ls = quotient_leaf_set(c->cd);
   { Workspace tmp; tmp.arena.base = nullptr; c->ws_bytes = plan_workspace(c, &tmp) + 4096; }
   guard.p = nullptr;
   *out = c; return 0;
@@ -668,7 +670,7 @@ static int prove_one(qpgpu_circuit* c, Workspace* w, hipStream_t s, const uint64
       quotient_eval_part(1, c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, pa, c->pl, s);
       (void)hipStreamWaitEvent(s, w->ev_gates, 0);
       quotient_sum(c->cd, pa, pb, w->q_vals, s);
-    } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s); }
+    } else quotient_eval(c->cd, c->d_cs_lde, w->wires_lde, w->zs_lde, betas, gammas, w->alpha_pows, nterms, pi_hash, w->q_vals, c->pl, s, c->quotient_ls && qp::opts().quotient_shared_loads != 0); }
   { ProfScope ps(w, s, PF_QUOTIENT_INTT, 8.0 * N * nch * 3);
     ntt_inplace(w->q_vals, N, nch, c->log_N, true, true, c->d_qpost, c->pl, s); }     // coset iNTT: leaf order in, coefficients out
   commit_coeffs(c, w, w->q_vals, c->Q, w->q_lde, w->q_dig, 3, salt, s);
