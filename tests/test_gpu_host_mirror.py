@@ -185,3 +185,32 @@ def test_prove_and_verify_from_files(pkg, tmp_path):
         pkg.WormholeProver.new_from_bytes(b"not a package" * 10, b"")
     with pytest.raises(RuntimeError, match="no synthetic witness source"):
         pkg.WormholeProver.new_from_files(str(tmp_path / "prover.qpkg"), str(tmp_path / "common.bin")).commit(pkg.SyntheticInputs.test_inputs())
+
+
+def test_prove_leaves_uses_one_blinding_key_and_one_salt_stream_per_proof(pkg, monkeypatch):
+    """every leaf of a batch draws its own prover randomness (the reference draws OsRng inside every prove): prove_leaves hands a
+    distinct 32-byte blinding key to each witness, two proofs of ONE statement in one batch differ, and under a caller-supplied salt key
+    the ChaCha8 stream continues from call to call instead of restarting at 0."""
+    import importlib
+    th = importlib.import_module("zk-circuits_amd.test_helpers")
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+    agg = pkg.WormholeProofAggregator(cd, pkg.TreeAggregationConfig(2, 3))
+    keys = []
+    real = cd._built.witness
+
+    def spy(inputs, blinding_key=None, out=None, threads=0):
+        keys.append(bytes(blinding_key)); return real(inputs, blinding_key, out=out, threads=threads)
+    monkeypatch.setattr(cd._built, "witness", spy)
+    same = [th.circuit_test_inputs() for _ in range(4)]
+    key = bytes(range(32))
+    agg.prove_leaves(same, salt_key=key)
+    first = [p.to_bytes() for p in agg.proofs_buffer]
+    assert len(set(keys)) == 4 and all(len(k) == 32 for k in keys)                      # one blinding key per leaf
+    assert len(set(first)) == 4                                                          # same statement, four different proofs
+    assert agg._salt_streams[key] == 4
+    agg.proofs_buffer = []
+    agg.prove_leaves(same[:2], salt_key=key)
+    assert agg._salt_streams[key] == 6 and len(set(keys)) == 6                           # streams 4, 5: no (key, stream) pair repeats
+    v = pkg.WormholeVerifier.new(None, circuit_data=cd)
+    assert v.verify_batch([pkg.ProofWithPublicInputs(b, 16) for b in first] + agg.proofs_buffer) == [True] * 6
+    agg.close()

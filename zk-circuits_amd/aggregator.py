@@ -55,6 +55,80 @@ def pipelined_batches(n, group, window, workers, witness, prove):
     return out
 
 
+def stream_proofs(n, circuit_data, buffers, witness, opts_for, witness_threads, provers=8):
+    """Independent proofs of one circuit as a continuous flow: `witness_threads` host threads generate witnesses (witness(i, wires, pis) fills
+    a page-locked matrix taken from `buffers`), `provers` threads each keep one qpgpu_prove in flight (the library picks its batch-mode
+    kernels when it sees several), a matrix goes back to the free list when its proof is done. No batch boundaries: the device never drains
+    while witnesses are available. opts_for(i) returns (ProveOpts, keep-alive) for proof i. Returns the n proofs' bytes in order."""
+    import queue
+    import threading
+    cd = circuit_data
+    free, ready = queue.Queue(), queue.Queue()
+    for wbuf in buffers:
+        free.put(wbuf)
+    out = [None] * n
+    nxt = [0]
+    left = [n]
+    lock = threading.Lock()
+    done = threading.Event(); failure = []
+
+    def fail(e):
+        with lock:
+            failure.append(e)
+        done.set()
+
+    def witness_thread():
+        while not done.is_set():
+            with lock:
+                i = nxt[0]
+                if i >= n:
+                    return
+                nxt[0] += 1
+            wires = None
+            while wires is None:
+                if done.is_set():
+                    return
+                try:
+                    wires = free.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            try:
+                pis = np.zeros(cd.num_public_inputs, dtype=np.uint64)
+                witness(i, wires, pis)
+                ready.put((i, wires, pis))
+            except Exception as e:                         # noqa: BLE001
+                fail(e)
+
+    def prover_thread():
+        buf = ctypes.create_string_buffer(cd.proof_size); ln = ctypes.c_size_t()
+        while not done.is_set():
+            try:
+                i, wires, pis = ready.get(timeout=0.05)
+            except queue.Empty:
+                continue
+            try:
+                o, keep = opts_for(i)                      # noqa: F841
+                ffi.check(ffi.lib().qpgpu_prove(cd._circuit, wires.ctypes.data, pis.ctypes.data_as(ffi.u64p), len(pis), ctypes.byref(o), buf, cd.proof_size, ctypes.byref(ln)))
+                free.put(wires)
+                out[i] = ctypes.string_at(buf, ln.value)
+                with lock:
+                    left[0] -= 1
+                    if left[0] == 0:
+                        done.set()
+            except Exception as e:                         # noqa: BLE001
+                fail(e)
+    threads = [threading.Thread(target=prover_thread, daemon=True) for _ in range(max(1, min(provers, n)))] + \
+              [threading.Thread(target=witness_thread, daemon=True) for _ in range(max(1, witness_threads))]
+    for t in threads:
+        t.start()
+    done.wait()
+    for t in threads:
+        t.join()
+    if failure:
+        raise failure[0]
+    return out
+
+
 class TreeAggregationConfig:
     def __init__(self, tree_branching_factor=DEFAULT_TREE_BRANCHING_FACTOR, tree_depth=DEFAULT_TREE_DEPTH):
         self.tree_branching_factor = tree_branching_factor
@@ -165,8 +239,20 @@ class WormholeProofAggregator:
         if not real or n == 1:
             prove([witness(i, i) for i in range(n)], 0)
             return
-        # host threads generate witnesses (the library releases the GIL) while the device proves the groups already complete
-        pipelined_batches(n, self.GROUP, window, outer, witness, prove)
+        # host threads generate witnesses (the library releases the GIL) while the device proves: a continuous flow of single proofs, or
+        # (QPGPU_TREE_STREAMING=0) device batches of GROUP leaves behind a bounded ring
+        if os.environ.get("QPGPU_TREE_STREAMING", "1") == "0":
+            pipelined_batches(n, self.GROUP, window, outer, witness, prove)
+            return
+
+        def fill(i, wires, pis):
+            built.witness(circuit_inputs_list[i].fill_targets(built.kind), proof_blinding_key(salt_seed, i), out=(wires, pis), threads=inner)
+
+        def opts_for(i):
+            o = ffi.ProveOpts(); o.salt_stream = base + i
+            return o, ffi.set_salt_key(o, key)
+        for raw in stream_proofs(n, cd, [b[0] for b in pool], fill, opts_for, outer):
+            self.push_proof(ProofWithPublicInputs(raw, cd.num_public_inputs))
 
     def close(self):
         """Releases the witness buffers (and the chunk prover's circuits and buffers)."""
@@ -367,6 +453,128 @@ class RecursiveChunkProver:
         # the host generates the next ones
         return pipelined_batches(len(chunks), self.GROUP, window, outer, witness, prove)
 
+    def prove_tree(self, leaf_proofs, config, provers=8):
+        """aggregate_to_tree (tree.rs:56-79) scheduled by DEPENDENCY instead of level by level: a node's witness generation starts when its
+        last child proof exists and its proof as soon as the witness does, so the latency-bound top of the tree (4, 2, 1 nodes: a witness and a
+        proof each) overlaps the device-bound levels below instead of following them. `provers` host threads each keep one qpgpu_prove in flight
+        (the library switches to its batch-mode kernel choices when it sees several). The tree must be uniform (branching^depth leaves).
+        With `salt_seed` set the root is byte-identical to the level-by-level tree's (node (level, i) takes the same blinding key and salt
+        stream either way). Returns the root AggregatedProof."""
+        import queue
+        import threading
+        b = config.tree_branching_factor
+        n = len(leaf_proofs)
+        depth = 0
+        while b ** depth < n:
+            depth += 1
+        if b ** depth != n or n < b:
+            raise ValueError("prove_tree needs branching^depth leaves")
+        for lvl in range(depth):                           # every level's circuit (built once, in this thread)
+            self._level_width.setdefault(lvl, b)
+            self.level(lvl, b)
+        leaves = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in leaf_proofs]
+        proofs = [leaves] + [[None] * (n // b ** (lvl + 1)) for lvl in range(depth)]      # proofs[l] = the proofs that ENTER level l
+        pending = [[b] * len(proofs[lvl + 1]) for lvl in range(depth)]
+        zk_key = None if self.salt_seed is not None else os.urandom(32)
+        shapes = {(self.level(l, b)[0].num_wires, self.level(l, b)[0].n) for l in range(depth)}
+        free = {}
+        for shape in shapes:                               # page-locked witness matrices per shape, handed out through a free list
+            mats = self._pool.setdefault(shape, [])
+            while len(mats) < self.GROUP * self.RING_GROUPS:
+                mats.append(ffi.witness_buffer(shape[0], shape[1], 0))
+            free[shape] = queue.Queue()
+            for m in mats[:self.GROUP * self.RING_GROUPS]:
+                free[shape].put(m[0])
+        # both queues hand out the HIGHEST level first: a parent whose children exist goes ahead of the level-0 backlog, so subtrees
+        # complete early and only the last subtree's chain to the root is left at the end
+        todo = queue.PriorityQueue()                       # (-level, index): witnesses to generate
+        ready = queue.PriorityQueue()                      # (-level, index, wires, pis): witnesses waiting for a prover thread
+        done = threading.Event(); failure = []
+        lock = threading.Lock()
+        outer, inner = witness_pool_shape(max(2, len(proofs[1])))
+
+        def fail(e):
+            with lock:
+                failure.append(e)
+            done.set()
+
+        def make_witness(level, i):
+            try:
+                cd, _inner_cd, cap, digest = self.level(level, b)
+                zk = bool(cd.desc.zero_knowledge)
+                seed = None if self.salt_seed is None else self.salt_seed + (level << 20)
+                wires = None
+                while wires is None:                       # a witness matrix of this shape (they come back from the prover threads)
+                    if done.is_set():
+                        return
+                    try:
+                        wires = free[(cd.num_wires, cd.n)].get(timeout=0.05)
+                    except queue.Empty:
+                        pass
+                pis = np.zeros(cd.num_public_inputs, dtype=np.uint64)
+                try:
+                    cd._built.witness(cd._built.aggregation_targets(cap, digest, proofs[level][b * i:b * (i + 1)]), proof_blinding_key(seed, i, b"node") if zk else None,
+                                      out=(wires, pis), threads=inner)
+                except ffi.CircuitError as e:
+                    free[(cd.num_wires, cd.n)].put(wires)
+                    raise RuntimeError("Failed to prove: a child proof of this node does not verify: %s" % e)
+                ready.put((-level, i, wires, pis))
+            except Exception as e:                         # noqa: BLE001
+                fail(e)
+
+        def witness_thread():
+            while not done.is_set():
+                try:
+                    neg_level, i = todo.get(timeout=0.05)
+                except queue.Empty:
+                    continue
+                make_witness(-neg_level, i)
+
+        def prover_thread():
+            while not done.is_set():
+                try:
+                    item = ready.get(timeout=0.05)
+                except queue.Empty:
+                    continue
+                level, i, wires, pis = -item[0], item[1], item[2], item[3]
+                try:
+                    cd = self.level(level, b)[0]
+                    o = ffi.ProveOpts()
+                    if cd.desc.zero_knowledge:              # proof i of a level: salt stream as in prove_chunks
+                        if self.salt_seed is not None:
+                            o.salt_stream = self.salt_seed + (level << 20) + i
+                            keep = ffi.set_salt_key(o, ffi.TEST_SALT_KEY)      # noqa: F841
+                        else:
+                            o.salt_stream = (level << 32) + i
+                            keep = ffi.set_salt_key(o, zk_key)                 # noqa: F841
+                    buf = ctypes.create_string_buffer(cd.proof_size); ln = ctypes.c_size_t()
+                    ffi.check(ffi.lib().qpgpu_prove(cd._circuit, wires.ctypes.data, pis.ctypes.data_as(ffi.u64p), len(pis), ctypes.byref(o), buf, cd.proof_size, ctypes.byref(ln)))
+                    free[(cd.num_wires, cd.n)].put(wires)
+                    pf = ctypes.string_at(buf, ln.value)
+                    proofs[level + 1][i] = pf
+                    if level + 1 == depth:
+                        done.set(); return
+                    with lock:
+                        pending[level + 1][i // b] -= 1
+                        go = pending[level + 1][i // b] == 0
+                    if go:
+                        todo.put((-(level + 1), i // b))
+                except Exception as e:                     # noqa: BLE001
+                    fail(e)
+        for i in range(len(proofs[1])):
+            todo.put((0, i))
+        threads = [threading.Thread(target=prover_thread, daemon=True) for _ in range(max(1, provers))] + \
+                  [threading.Thread(target=witness_thread, daemon=True) for _ in range(max(1, outer))]
+        for t in threads:
+            t.start()
+        done.wait()
+        for t in threads:
+            t.join()
+        if failure:
+            raise failure[0]
+        cd_root = self.level(depth - 1, b)[0]
+        return AggregatedProof(ProofWithPublicInputs(proofs[depth][0], cd_root.num_public_inputs), cd_root)
+
     GROUP = 8                           # node proofs per device batch
     RING_GROUPS = 3                     # witness buffers kept per level shape: RING_GROUPS * GROUP
 
@@ -404,8 +612,15 @@ def aggregate_level(proofs, chunk_prover, config, level, first_index=0):
     return _prove_chunks(chunk_prover, chunks, level, first_index)
 
 
-def aggregate_to_tree(leaf_proofs, config, chunk_prover):
-    """tree.rs:56-79: aggregate level by level until one proof is left."""
+def aggregate_to_tree(leaf_proofs, config, chunk_prover, streaming=None):
+    """tree.rs:56-79: aggregate level by level until one proof is left. A prover that can schedule the whole tree by dependency
+    (RecursiveChunkProver.prove_tree) does so for uniform trees of more than one level unless `streaming` is False (QPGPU_TREE_STREAMING=0
+    switches the default off); same root statement, and with a salt seed the same root bytes."""
+    if streaming is None:
+        streaming = os.environ.get("QPGPU_TREE_STREAMING", "1") != "0"
+    b, n = config.tree_branching_factor, len(leaf_proofs)
+    if streaming and hasattr(chunk_prover, "prove_tree") and n > b and n == config.num_leaf_proofs:
+        return chunk_prover.prove_tree(list(leaf_proofs), config)
     proofs = aggregate_level(list(leaf_proofs), chunk_prover, config, 0)
     level = 1
     while len(proofs) > 1:

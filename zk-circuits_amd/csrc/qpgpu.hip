@@ -218,6 +218,7 @@ static void ws_destroy(Workspace* w) {
 
 using qp::usable_cpus;          // csrc/hostcpus.h: affinity mask, capped by the cgroup CPU quota, divided by the ranks of this node
 static std::atomic<uint64_t> g_handoff_fallbacks{0};
+static std::atomic<int> g_proofs_in_flight{0};          // qpgpu_prove calls running right now in this process
 extern "C" int qpgpu_usable_host_cpus(void) { return qp::usable_cpus_uncached(); }
 extern "C" uint64_t qpgpu_handoff_fallbacks(void) { return g_handoff_fallbacks.load(std::memory_order_relaxed); }
 
@@ -872,7 +873,14 @@ int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_
   HIP_TRY(hipSetDevice(c->device));
   Workspace* w = nullptr; int rc = ws_acquire(c, &w); if (rc) return rc;
   hipStream_t s = (opts && opts->stream) ? (hipStream_t)opts->stream : w->stream;
+  // A host that keeps several proofs in flight by calling qpgpu_prove from several threads (the reference's rayon workers, tree.rs:100;
+  // aggregator.py's dependency-driven tree) gets the kernel choices of qpgpu_prove_batch: what is best for a lone proof (side-stream
+  // quotient halves, the 16-lane form for mid-sized tree levels) is not when other proofs fill the chip. Same bytes either way.
+  struct InFlight { int others; InFlight() : others(g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed)) {} ~InFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } fl;
+  w->batch_mode = fl.others > 0;
+  w->cores_to_spare = usable_cpus() >= 2 * (fl.others + 1);
   rc = prove_one(c, w, s, wires, public_inputs, opts, salt_source(opts, 0, c->N), out);
+  w->batch_mode = false; w->cores_to_spare = true;
   if (rc != 0) {                              // nothing of this proof may still run when the workspace is recycled, and no byte derived from
     (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(w->side); w->pev_used = 0;      // a refused witness may stay in the caller's buffer
     memset(out, 0, c->lay.total);
