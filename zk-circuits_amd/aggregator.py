@@ -55,6 +55,19 @@ def pipelined_batches(n, group, window, workers, witness, prove):
     return out
 
 
+class _fast_thread_switching:
+    """The scheduler threads of stream_proofs / prove_tree spend their time inside library calls (GIL released) and need the interpreter only
+    for a few microseconds between them; CPython's default 5 ms switch interval would let one of them sit on a finished proof that long."""
+
+    def __enter__(self):
+        import sys
+        self.old = sys.getswitchinterval(); sys.setswitchinterval(1e-4)
+
+    def __exit__(self, *a):
+        import sys
+        sys.setswitchinterval(self.old)
+
+
 def stream_proofs(n, circuit_data, buffers, witness, opts_for, witness_threads, provers=8):
     """Independent proofs of one circuit as a continuous flow: `witness_threads` host threads generate witnesses (witness(i, wires, pis) fills
     a page-locked matrix taken from `buffers`), `provers` threads each keep one qpgpu_prove in flight (the library picks its batch-mode
@@ -92,6 +105,8 @@ def stream_proofs(n, circuit_data, buffers, witness, opts_for, witness_threads, 
                     wires = free.get(timeout=0.05)
                 except queue.Empty:
                     pass
+            if done.is_set():
+                return
             try:
                 pis = np.zeros(cd.num_public_inputs, dtype=np.uint64)
                 witness(i, wires, pis)
@@ -106,6 +121,8 @@ def stream_proofs(n, circuit_data, buffers, witness, opts_for, witness_threads, 
                 i, wires, pis = ready.get(timeout=0.05)
             except queue.Empty:
                 continue
+            if wires is None:
+                return
             try:
                 o, keep = opts_for(i)                      # noqa: F841
                 ffi.check(ffi.lib().qpgpu_prove(cd._circuit, wires.ctypes.data, pis.ctypes.data_as(ffi.u64p), len(pis), ctypes.byref(o), buf, cd.proof_size, ctypes.byref(ln)))
@@ -119,11 +136,14 @@ def stream_proofs(n, circuit_data, buffers, witness, opts_for, witness_threads, 
                 fail(e)
     threads = [threading.Thread(target=prover_thread, daemon=True) for _ in range(max(1, min(provers, n)))] + \
               [threading.Thread(target=witness_thread, daemon=True) for _ in range(max(1, witness_threads))]
-    for t in threads:
-        t.start()
-    done.wait()
-    for t in threads:
-        t.join()
+    with _fast_thread_switching():
+        for t in threads:
+            t.start()
+        done.wait()
+        for _ in threads:                                  # wake whoever still waits on a queue
+            ready.put((-1, None, None)); free.put(None)
+        for t in threads:
+            t.join()
     if failure:
         raise failure[0]
     return out
@@ -511,6 +531,8 @@ class RecursiveChunkProver:
                         wires = free[(cd.num_wires, cd.n)].get(timeout=0.05)
                     except queue.Empty:
                         pass
+                if done.is_set():
+                    return
                 pis = np.zeros(cd.num_public_inputs, dtype=np.uint64)
                 try:
                     cd._built.witness(cd._built.aggregation_targets(cap, digest, proofs[level][b * i:b * (i + 1)]), proof_blinding_key(seed, i, b"node") if zk else None,
@@ -528,6 +550,8 @@ class RecursiveChunkProver:
                     neg_level, i = todo.get(timeout=0.05)
                 except queue.Empty:
                     continue
+                if i < 0:
+                    return
                 make_witness(-neg_level, i)
 
         def prover_thread():
@@ -537,6 +561,8 @@ class RecursiveChunkProver:
                 except queue.Empty:
                     continue
                 level, i, wires, pis = -item[0], item[1], item[2], item[3]
+                if wires is None:
+                    return
                 try:
                     cd = self.level(level, b)[0]
                     o = ffi.ProveOpts()
@@ -565,11 +591,16 @@ class RecursiveChunkProver:
             todo.put((0, i))
         threads = [threading.Thread(target=prover_thread, daemon=True) for _ in range(max(1, provers))] + \
                   [threading.Thread(target=witness_thread, daemon=True) for _ in range(max(1, outer))]
-        for t in threads:
-            t.start()
-        done.wait()
-        for t in threads:
-            t.join()
+        with _fast_thread_switching():
+            for t in threads:
+                t.start()
+            done.wait()
+            for _ in threads:                              # wake whoever still waits on a queue
+                todo.put((10 ** 9, -1)); ready.put((10 ** 9, -1, None, None))
+                for q in free.values():
+                    q.put(None)
+            for t in threads:
+                t.join()
         if failure:
             raise failure[0]
         cd_root = self.level(depth - 1, b)[0]
@@ -614,12 +645,14 @@ def aggregate_level(proofs, chunk_prover, config, level, first_index=0):
 
 def aggregate_to_tree(leaf_proofs, config, chunk_prover, streaming=None):
     """tree.rs:56-79: aggregate level by level until one proof is left. A prover that can schedule the whole tree by dependency
-    (RecursiveChunkProver.prove_tree) does so for uniform trees of more than one level unless `streaming` is False (QPGPU_TREE_STREAMING=0
+    (RecursiveChunkProver.prove_tree) does so for uniform trees of three or more levels unless `streaming` is False (QPGPU_TREE_STREAMING=0
     switches the default off); same root statement, and with a salt seed the same root bytes."""
     if streaming is None:
         streaming = os.environ.get("QPGPU_TREE_STREAMING", "1") != "0"
     b, n = config.tree_branching_factor, len(leaf_proofs)
-    if streaming and hasattr(chunk_prover, "prove_tree") and n > b and n == config.num_leaf_proofs:
+    # (trees of one or two levels have no latency-bound top to hide: one device batch per level is the cheaper schedule there — 80 vs 97 ms
+    # for the reference's (5, 2) bench line, 289 vs 244 ms the other way round for (2, 5); profiles/r03_stream_ab.txt)
+    if streaming and hasattr(chunk_prover, "prove_tree") and n == config.num_leaf_proofs and config.tree_depth >= 3:
         return chunk_prover.prove_tree(list(leaf_proofs), config)
     proofs = aggregate_level(list(leaf_proofs), chunk_prover, config, 0)
     level = 1
