@@ -142,3 +142,30 @@ def test_two_ranks_sharing_the_gpu_build_the_same_tree(tmp_path):
                         "--master-port", "29652", str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_dependency_driven_tree_equals_the_level_by_level_tree():
+    """RecursiveChunkProver.prove_tree (a parent starts when its children exist, prover threads keep single proofs in flight) against
+    aggregate_level by aggregate_level (tree.rs:56-79) on the same 32 zk leaves: with a salt seed every node gets the same blinding rows and
+    salts under either schedule, so the roots are byte-identical; a forged leaf makes the scheduler raise (its worker threads end, nothing hangs)."""
+    import threading
+    n, depth = 32, 5
+    cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
+    cfg = pkg.TreeAggregationConfig(2, depth)
+    agg = pkg.WormholeProofAggregator(cd, cfg)
+    agg.prove_leaves(_inputs(n), salt_seed=SEED)
+    leaves = [p.to_bytes() for p in agg.proofs_buffer]
+    prover = pkg.RecursiveChunkProver(cd, salt_seed=SEED)
+    a = aggregator.aggregate_to_tree(leaves, cfg, prover, streaming=False)
+    b = aggregator.aggregate_to_tree(leaves, cfg, prover, streaming=True)
+    assert a.proof.to_bytes() == b.proof.to_bytes()
+    pkg.WormholeVerifier.new(None, circuit_data=b.circuit_data).verify(b.proof)
+    assert b.proof.public_inputs == [x for p in agg.proofs_buffer for x in p.public_inputs]
+    before = threading.active_count()
+    bad = list(leaves); forged = bytearray(bad[17]); forged[5000] ^= 1; bad[17] = bytes(forged)
+    with pytest.raises(RuntimeError, match="does not verify"):
+        aggregator.aggregate_to_tree(bad, cfg, prover, streaming=True)
+    assert threading.active_count() <= before                      # the scheduler's threads are gone
+    c = aggregator.aggregate_to_tree(leaves, cfg, prover, streaming=True)      # and the prover is usable afterwards
+    assert c.proof.to_bytes() == a.proof.to_bytes()
+    prover.close(); agg.close()

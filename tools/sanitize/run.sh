@@ -6,11 +6,11 @@
 # The in-tree library is restored afterwards.
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
-SRC="$R/zk-circuits_amd/circuit/builder.cc $R/zk-circuits_amd/circuit/circuits.cc $R/zk-circuits_amd/circuit/recursion.cc"
+SRC="$R/zk-circuits_amd/circuit/builder.cc $R/zk-circuits_amd/circuit/circuits.cc $R/zk-circuits_amd/circuit/recursion.cc $R/zk-circuits_amd/circuit/mutation.cc"
 cp $R/zk-circuits_amd/libqpcircuit.so /tmp/libqpcircuit.so.bak
 trap 'cp /tmp/libqpcircuit.so.bak $R/zk-circuits_amd/libqpcircuit.so' EXIT
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unused-function $SRC -pthread -o $R/zk-circuits_amd/libqpcircuit.so
-(cd $R && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" python -m pytest tests/test_wormhole_circuit.py tests/test_aggregation_circuit.py -x -q -s | tail -2)
+(cd $R && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" python -m pytest tests/test_wormhole_circuit.py tests/test_aggregation_circuit.py tests/test_hint_soundness.py -x -q -s | tail -2)
 cp /tmp/libqpcircuit.so.bak $R/zk-circuits_amd/libqpcircuit.so
 mkdir -p /tmp/tsan
 (cd $R && python3 - <<'PY'
