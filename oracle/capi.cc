@@ -17,6 +17,8 @@ extern "C" {
 const char* orc_last_error() { return g_err.c_str(); }
 void orc_round_constants(u64* out) { memcpy(out, poseidon_round_constants(), 360 * 8); }
 void orc_permute(u64* st) { poseidon_permute(st); }
+void orc_set_poseidon_fast(int on) { poseidon_set_fast(on != 0); }
+int orc_poseidon_is_fast() { return poseidon_is_fast() ? 1 : 0; }
 void orc_permute_generic(u64* st) { poseidon_permute_generic(st); }
 void orc_hash_no_pad(const u64* x, size_t len, u64* out) { Hash h = hash_no_pad(x, len); memcpy(out, h.data(), 32); }
 void orc_hash_or_noop(const u64* x, size_t len, u64* out) { Hash h = hash_or_noop(x, len); memcpy(out, h.data(), 32); }

@@ -145,7 +145,27 @@ inline u64 dot11(const u64* a, const u64* x, u64 c0, u64 x0) {
   return d;
 }
 }
+// The oracle's PRIMARY permutation runs the literal rounds of SURVEY.md App. A.2 — add constants, S-box (all lanes in full rounds, lane 0 in
+// partial rounds), the MDS product — from the primary constants alone (round constants + MDS). The derived fast form below shares its
+// tables with the product (one generator, tools/gen_poseidon_fast.py): a checker must not lean on what it checks, so the fast form is
+// opt-in (poseidon_set_fast: bench.py's cpu_baseline timing leg, where the CPU side should be as fast as it can) and tests compare the two.
+static bool g_poseidon_fast = false;
+void poseidon_set_fast(bool on) { g_poseidon_fast = on; }
+bool poseidon_is_fast() { return g_poseidon_fast; }
+static void poseidon_permute_fast(u64 st[12]);
 void poseidon_permute(u64 st[12]) {
+  if (g_poseidon_fast) { poseidon_permute_fast(st); return; }
+  const u64* rc = poseidon_round_constants();
+  for (int i = 0; i < 12; i++) st[i] = addc_lazy(st[i], rc[i]);
+  for (int r = 0; r < N_ROUNDS; r++) {
+    const bool full = r < N_FULL_HALF || r >= N_FULL_HALF + N_PARTIAL;
+    if (full) for (int i = 0; i < 12; i++) st[i] = sbox_lazy(st[i]);
+    else st[0] = sbox_lazy(st[0]);
+    mds_rc(st, r + 1 < N_ROUNDS ? rc + 12 * (r + 1) : nullptr);          // the MDS product, then the next round's constants
+  }
+  for (int i = 0; i < 12; i++) if (st[i] >= P) st[i] -= P;
+}
+static void poseidon_permute_fast(u64 st[12]) {
   const u64* rc = poseidon_round_constants();
   for (int i = 0; i < 12; i++) st[i] = addc_lazy(st[i], rc[i]);
   for (int r = 0; r < N_FULL_HALF; r++) {

@@ -19,7 +19,9 @@ const u64* poseidon_round_constants();  // 360 values, index 12*r+i (generated: 
 typedef std::array<u64, 12> State;
 typedef std::array<u64, 4> Hash;
 
-void poseidon_permute(u64 st[12]);
+void poseidon_permute(u64 st[12]);            // literal rounds (primary constants only) unless poseidon_set_fast(true)
+void poseidon_set_fast(bool on);               // opt into the derived fast partial rounds (shared tables with the product: timing only)
+bool poseidon_is_fast();
 void poseidon_permute_generic(u64 st[12]);
 Hash hash_no_pad(const u64* x, size_t len);
 Hash hash_or_noop(const u64* x, size_t len);

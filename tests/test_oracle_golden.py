@@ -233,3 +233,31 @@ def test_dummy_proof_merkle_openings_are_consistent(name):
             for sib in q["layer_paths"][l]:
                 dg = h2(sib, dg) if i & 1 else h2(dg, sib); i >>= 1
             assert np.array_equal(dg, p["fri_caps"][l][i])
+
+
+def test_the_oracle_checks_with_the_literal_rounds_and_its_fast_form_agrees():
+    """The oracle's primary permutation is the literal 30 rounds on the primary constants (round constants + MDS); the derived fast partial
+    rounds share their tables with the product (one generator) and are opt-in for timing only. The two forms, and the field-generic
+    restatement, agree on random states and on a whole proof."""
+    import ctypes
+    import numpy as np
+    from harness import SynthCircuit, OracleCircuit, oracle, ptr, u64p, P
+    L = oracle()
+    L.orc_permute.argtypes = [u64p]; L.orc_permute_generic.argtypes = [u64p]
+    assert L.orc_poseidon_is_fast() == 0
+    rng = np.random.default_rng(11)
+    st = rng.integers(0, P, size=(300, 12), dtype=np.uint64); st[0] = 0; st[1] = P - 1
+    lit, fast, gen = st.copy(), st.copy(), st.copy()
+    for i in range(len(st)):
+        L.orc_permute(ptr(lit[i])); L.orc_permute_generic(ptr(gen[i]))
+    try:
+        L.orc_set_poseidon_fast(1)
+        for i in range(len(st)):
+            L.orc_permute(ptr(fast[i]))
+        sc = SynthCircuit("T"); oc = OracleCircuit(sc.desc); w, p = sc.witness(5)
+        pf_fast = oc.prove(w, p)
+    finally:
+        L.orc_set_poseidon_fast(0)
+    assert np.array_equal(lit, gen) and np.array_equal(lit, fast)
+    assert int(lit[0][0]) == 0x3c18a9786cb0b359                                  # permute([0; 12])[0], SURVEY.md App. A.2
+    assert oc.prove(w, p) == pf_fast and oc.verify(pf_fast) is None
