@@ -129,7 +129,8 @@ int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit* c, uint64_t* out_cap
 size_t qpgpu_proof_size(const qpgpu_circuit* c);
 
 /* prove_with_partition_witness: full witness matrix -> ProofWithPublicInputs::to_bytes().
- * wires: [num_wires][n] column-major. Re-entrant: each call uses its own stream + workspace. */
+ * wires: [num_wires][n] column-major. Re-entrant: each call uses its own stream + workspace; when several calls are in flight in the
+ * process (the reference's rayon workers, tree.rs:100) they run with qpgpu_prove_batch's kernel choices. Same bytes either way. */
 int qpgpu_prove(qpgpu_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, size_t num_public_inputs,
                 const qpgpu_prove_opts* opts, uint8_t* out, size_t out_cap, size_t* out_len);
 
