@@ -473,13 +473,15 @@ class RecursiveChunkProver:
         # the host generates the next ones
         return pipelined_batches(len(chunks), self.GROUP, window, outer, witness, prove)
 
-    def prove_tree(self, leaf_proofs, config, provers=8):
+    def prove_tree(self, leaf_proofs, config, provers=8, first_leaf=0):
         """aggregate_to_tree (tree.rs:56-79) scheduled by DEPENDENCY instead of level by level: a node's witness generation starts when its
         last child proof exists and its proof as soon as the witness does, so the latency-bound top of the tree (4, 2, 1 nodes: a witness and a
         proof each) overlaps the device-bound levels below instead of following them. `provers` host threads each keep one qpgpu_prove in flight
         (the library switches to its batch-mode kernel choices when it sees several). The tree must be uniform (branching^depth leaves).
         With `salt_seed` set the root is byte-identical to the level-by-level tree's (node (level, i) takes the same blinding key and salt
-        stream either way). Returns the root AggregatedProof."""
+        stream either way). `first_leaf`: position of leaf_proofs[0] among the leaves of a larger tree whose complete subtree this is (a rank of
+        aggregate_to_tree_distributed): node i of a level then counts as node first_leaf / branching^(level+1) + i of that level. Returns the
+        root AggregatedProof."""
         import queue
         import threading
         b = config.tree_branching_factor
@@ -535,7 +537,8 @@ class RecursiveChunkProver:
                     return
                 pis = np.zeros(cd.num_public_inputs, dtype=np.uint64)
                 try:
-                    cd._built.witness(cd._built.aggregation_targets(cap, digest, proofs[level][b * i:b * (i + 1)]), proof_blinding_key(seed, i, b"node") if zk else None,
+                    cd._built.witness(cd._built.aggregation_targets(cap, digest, proofs[level][b * i:b * (i + 1)]),
+                                      proof_blinding_key(seed, first_leaf // b ** (level + 1) + i, b"node") if zk else None,
                                       out=(wires, pis), threads=inner)
                 except ffi.CircuitError as e:
                     free[(cd.num_wires, cd.n)].put(wires)
@@ -568,7 +571,7 @@ class RecursiveChunkProver:
                     o = ffi.ProveOpts()
                     if cd.desc.zero_knowledge:              # proof i of a level: salt stream as in prove_chunks
                         if self.salt_seed is not None:
-                            o.salt_stream = self.salt_seed + (level << 20) + i
+                            o.salt_stream = self.salt_seed + (level << 20) + first_leaf // b ** (level + 1) + i
                             keep = ffi.set_salt_key(o, ffi.TEST_SALT_KEY)      # noqa: F841
                         else:
                             o.salt_stream = (level << 32) + i
@@ -675,6 +678,16 @@ def aggregate_to_tree_distributed(local_leaf_proofs, config, chunk_prover, proof
     proofs, level, spread = list(local_leaf_proofs), 0, True          # spread: every rank still holds its own run
     total = len(proofs) * world
     while total > 1:
+        if spread and level == 0 and hasattr(chunk_prover, "prove_tree") and os.environ.get("QPGPU_TREE_STREAMING", "1") != "0":
+            k = 0                                                       # this rank's leaves as a complete subtree of k >= 3 levels: scheduled by dependency
+            while b ** k < len(proofs):
+                k += 1
+            if k >= 3 and b ** k == len(proofs):
+                proofs = [chunk_prover.prove_tree(proofs, TreeAggregationConfig(b, k), first_leaf=rank * len(proofs)).proof]
+                for _ in range(k):
+                    total = (total + b - 1) // b
+                level = k
+                continue
         if spread and len(proofs) % b == 0 and len(proofs) >= b:
             proofs = [p.proof for p in aggregate_level(proofs, chunk_prover, config, level, first_index=rank * (len(proofs) // b))]
         else:
