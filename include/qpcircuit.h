@@ -94,11 +94,12 @@ typedef struct qpv_vote_inputs {
 int qpv_fill_targets(const qpv_vote_inputs* in, uint64_t* inputs, size_t cap, size_t* len);
 
 /* ---- aggregation (wormhole/aggregator/src/circuits/tree.rs:106-143, aggregate_chunk): the circuit of one tree node — for each of
- * `num_proofs` children of the circuit `inner` (a circuit of this library: leaf gate set, standard_recursion(_zk)_config), verify_proof
+ * `num_proofs` children of the circuit `inner` (a circuit of this library — a leaf circuit or another node — under standard_recursion(_zk)_config), verify_proof
  * in-circuit against verifier data given as (private) inputs, and the children's public inputs, concatenated, as the node's public inputs.
  * The node circuit takes the inner circuit's config (tree.rs:111): zero-knowledge children give a zero-knowledge node.
- * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built from the leaf gate set; its layout is
- * unpinned like every circuit here. */
+ * The in-circuit verifier is this repo's own (zk-circuits_amd/circuit/recursion.cc), built on the leaf gate set plus upstream's recursion
+ * gates (ArithmeticExtension, Reducing, ReducingExtension, RandomAccess, CosetInterpolation, PoseidonMds: 8.8 k rows for two zk leaf proofs);
+ * its layout is unpinned like every circuit here. */
 int qpc_aggregation_circuit_build(const qpgpu_circuit_desc* inner, uint32_t num_proofs, qpc_circuit** out);
 /* The same with the node's own zero-knowledge setting: 2 = as the children (what the function above and the reference do), 0 / 1 = off / on.
  * A node's witness is made of public data only (its children's proofs and their verifier data), so a node without blinding rows gives nothing

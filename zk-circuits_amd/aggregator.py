@@ -4,7 +4,7 @@ circuits/tree.rs:24-103, util.rs:11-29).
 Scope: the buffer semantics and error behaviour of push_proof / aggregate, the sharding of
 independent leaf proofs (one per GPU stream / per rank), the RCCL gather of the fixed-size proof blobs that precedes the
 aggregator step, and the aggregation tree itself: `RecursiveChunkProver` is aggregate_chunk (tree.rs:106-143) — the node circuit
-verifies its children in-circuit (libqpcircuit's own recursive verifier on the leaf gate set, include/qpcircuit.h; qp-plonky2's is not
+verifies its children in-circuit (libqpcircuit's own recursive verifier on the leaf + recursion gate set, include/qpcircuit.h; qp-plonky2's is not
 on disk, so node circuits are this repo's layout, not upstream's), its witness is generated on the host and proved on the device.
 `aggregate()` returns the padded leaf set without a chunk prover and the root proof with one.
 """

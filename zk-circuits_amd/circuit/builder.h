@@ -1,5 +1,6 @@
-// Circuit builder + witness generator for the leaf gate set (Noop, Constant{2}, PublicInput, BaseSum<2>{63}, Arithmetic{20}, Poseidon)
-// under standard_recursion(_zk)_config: 135 wires, 80 routed, 2 constants per gate. Host-only C++.
+// Circuit builder + witness generator for the leaf gate set (Noop, Constant{2}, PublicInput, BaseSum<2>{63}, Arithmetic{20}, Poseidon) and the
+// recursive verifier's gates (ArithmeticExtension, Reducing, ReducingExtension, RandomAccess, PoseidonMds, CosetInterpolation, Exponentiation;
+// SURVEY.md App. D) under standard_recursion(_zk)_config: 135 wires, 80 routed, 2 constants per gate. Host-only C++.
 //
 // This is this repo's own builder: it offers the operations the reference's circuit definitions call on plonky2's CircuitBuilder
 // (wormhole/circuit/src/{nullifier,unspendable_account,storage_proof/mod,substrate_account}.rs, common/src/gadgets.rs, voting/src/lib.rs)
