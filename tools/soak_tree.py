@@ -5,11 +5,11 @@ import torch; torch.cuda.init()
 pkg = importlib.import_module("zk-circuits_amd"); th = importlib.import_module("zk-circuits_amd.test_helpers")
 cd = pkg.WormholeCircuitData.get(pkg.CircuitConfig.standard_recursion_zk_config())
 prover = pkg.RecursiveChunkProver(cd)
-cfg = pkg.TreeAggregationConfig(2, 3)
+cfg = pkg.TreeAggregationConfig(2, int(os.environ.get("SOAK_DEPTH", "3")))          # depth >= 3: the dependency-driven scheduler (threads) runs every iteration
 t0 = time.time()
-for it in range(25):
+for it in range(int(os.environ.get("SOAK_ITERS", "25"))):
     agg = pkg.WormholeProofAggregator(cd, cfg)
-    ins = [th.circuit_test_inputs() for _ in range(7)]
+    ins = [th.circuit_test_inputs() for _ in range(cfg.num_leaf_proofs - 1)]          # one short: the dummy proof pads the last leaf
     for i, ci in enumerate(ins): ci.public.exit_account = pkg.BytesDigest(bytes([it & 0x7f, i] + [0] * 30))
     agg.prove_leaves(ins)
     root = agg.aggregate(chunk_prover=prover)

@@ -573,10 +573,12 @@ class CircuitPackage:
 
 
 class _PinnedBlock:
-    """Owner of one qpgpu_host_alloc block (freed when the last numpy view of it goes away)."""
+    """Owner of one qpgpu_host_alloc block, exposed to numpy through the array interface: the arrays made from it (and their views) hold a
+    reference to this object as their base, so the block is freed when the last of them goes away — no registry, nothing to leak."""
 
-    def __init__(self, ptr_):
+    def __init__(self, ptr_, shape):
         self.ptr = ptr_
+        self.__array_interface__ = {"data": (ptr_, False), "shape": tuple(shape), "typestr": "<u8", "version": 3}
 
     def __del__(self):
         try:
@@ -589,28 +591,23 @@ class _PinnedBlock:
 def witness_buffer(num_wires, n, num_public_inputs, pinned=True):
     """A reusable (wires [num_wires][n], public_inputs) pair for BuiltCircuit.witness(out=...). With `pinned` the matrix lives in page-locked
     host memory (qpgpu_host_alloc), so qpgpu_prove(_batch) uploads it with one DMA transfer instead of staging it through bounce buffers on
-    the proving thread; if page-locked memory cannot be had (no device in this process) it is ordinary memory."""
+    the proving thread; if page-locked memory cannot be had (no device in this process) it is ordinary memory. The memory goes back when the
+    array (and every view of it) is garbage."""
     pis = np.zeros(num_public_inputs, dtype=np.uint64)
     if pinned:
         try:
             p = ctypes.c_void_p()
             if lib().qpgpu_host_alloc(num_wires * n * 8, ctypes.byref(p)) == 0 and p.value:
-                block = _PinnedBlock(p.value)
-                raw = (ctypes.c_uint64 * (num_wires * n)).from_address(p.value)
-                wires = np.frombuffer(raw, dtype=np.uint64).reshape(num_wires, n)
-                _PINNED_OWNERS[wires.ctypes.data] = block          # keeps the block alive as long as the entry stays (release_witness_buffer drops it)
+                wires = np.asarray(_PinnedBlock(p.value, (num_wires, n)))
+                assert wires.ctypes.data == p.value and wires.flags.c_contiguous and wires.dtype == np.uint64
                 return wires, pis
         except Exception:
             pass
     return np.empty((num_wires, n), dtype=np.uint64), pis
 
 
-_PINNED_OWNERS = {}
-
-
 def release_witness_buffer(buf):
-    """Frees the page-locked block behind a witness_buffer (no-op for ordinary memory). The arrays must not be used afterwards."""
-    _PINNED_OWNERS.pop(buf[0].ctypes.data, None)
+    """Kept for callers that release explicitly: dropping the arrays is what frees a page-locked block."""
 
 
 COMM_ID_BYTES = 128          # include/qpgpu.h QPGPU_COMM_ID_BYTES
