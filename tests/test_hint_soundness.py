@@ -183,3 +183,29 @@ def test_the_sweep_finds_planted_under_constrained_hints():
     assert sum(v for (k, m, vd), v in seen.items() if k == "extension inverse" and vd in ("SURVIVED", "benign")) > 0, seen
     assert seen[("lo/hi halves", 3, "SURVIVED")] > 0, seen                                      # missing canonicity check found
     assert not [k for k in seen if k[0] == "lo/hi halves" and k[1] in (0, 1, 4) and k[2] == "SURVIVED"], seen   # sum and ranges are pinned
+
+
+def test_node_over_node_every_hint():
+    """One level up: a node that verifies a NODE proof evaluates the recursion gates' own constraints in-circuit (ArithmeticExtension, Reducing,
+    ReducingExtension, RandomAccess, PoseidonMds in the extension algebra). Same sweep on that circuit: leaf = the nullifier fragment on the
+    reference's inputs, level-0 node proved by the oracle, level-1 node mutated."""
+    leaf = BuiltCircuit(QPC_NULLIFIER, False)
+    w, p = leaf.witness(_wormhole_inputs(QPC_NULLIFIER))
+    ol = OracleCircuit(leaf.desc)
+    n0 = BuiltCircuit.aggregation(leaf.desc, 2, False)
+    w0, p0 = n0.witness(n0.aggregation_targets(ol.cap(), leaf.desc.circuit_digest, [ol.prove(w, p)] * 2))
+    o0 = OracleCircuit(n0.desc)
+    pf0 = o0.prove(w0, p0)
+    assert o0.verify(pf0) is None and n0.desc.num_gates > 6                       # the inner circuit carries recursion gates
+    n1 = BuiltCircuit.aggregation(n0.desc, 1, False)
+    x1 = n1.aggregation_targets(o0.cap(), n0.desc.circuit_digest, [pf0])
+    res, stats = sweep(n1, x1, 0, full_every=1499)
+    t = assert_sound(res, "node over a node proof", min_hints=2000)
+    assert stats["full"] >= 3 and ("RandomAccess bits / claimed element", "killed") in t and ("Reducing accumulators", "killed") in t
+    flips, _ = sweep(n1, x1, 1, full_every=2999, modes=1)
+    from harness import replay_transcript
+    d = n0.desc
+    selected = {q >> (d.degree_bits + d.fri_rate_bits - d.fri_cap_height) for q in replay_transcript(d, pf0)["query_indices"]}
+    free_cap = {4 * j + e for j in range(1 << d.fri_cap_height) if j not in selected for e in range(4)}
+    assert {r.index for r in flips if r.verdict == 2} == free_cap
+    assert all(r.verdict in (0, 5) for r in flips if r.index not in free_cap)
