@@ -2,10 +2,10 @@
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
     import numpy as np, torch
     torch.cuda.init()
-    import harness as H
+    import importlib; H = importlib.import_module("zk-circuits_amd.ffi")          # the product binding only (no oracle in a measurement tool)
     sc = H.SynthCircuit(os.environ.get("PRESET", "B")); gc = H.GpuCircuit(sc.desc)
     nb = int(os.environ.get("NB", "32"))
     wd, pl = [], []

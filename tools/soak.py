@@ -1,10 +1,10 @@
 """Stability soak (run on the GPU box): thousands of proofs through every entry point must give identical bytes —
 single calls, concurrent qpgpu_prove from several threads on one circuit, and qpgpu_prove_batch, interleaved."""
 import sys, os, threading, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 torch.cuda.init()
-import harness as H
+import importlib; H = importlib.import_module("zk-circuits_amd.ffi")          # the product binding only (no oracle in a measurement tool)
 for preset in ("B", "A", "RT"):
     sc = H.SynthCircuit(preset); gc = H.GpuCircuit(sc.desc)
     wit = [sc.witness(900 + i) for i in range(4)]
