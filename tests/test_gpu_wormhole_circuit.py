@@ -281,13 +281,13 @@ def test_aggregate_proofs_into_tree_like_the_reference_tests(zk):
 
 @pytest.mark.parametrize("seed", [100, 101, 103])
 def test_builder_programs_with_the_recursion_gates_prove_byte_equal_to_the_oracle(seed):
-    """Random builder programs that mix in the recursive verifier's gates (ArithmeticExtension, Reducing, ReducingExtension, RandomAccess,
-    PoseidonMds, CosetInterpolation, Exponentiation; four selector groups, six constant columns): the device proof of the generated witness is
-    byte-equal to the oracle's and both verifiers accept it — the device's gate kernels on rows the builder placed, Exponentiation included
-    (the node circuit does not use that one)."""
+    """Random builder programs that mix in the recursive verifier's gates (ArithmeticExtension, MulExtension, Reducing, ReducingExtension, RandomAccess,
+    PoseidonMds, CosetInterpolation, Exponentiation: all fourteen gate types; five selector groups, seven constant columns): the device proof of the generated witness is
+    byte-equal to the oracle's and both verifiers accept it — the device's gate kernels on rows the builder placed, Exponentiation and
+    MulExtension included (the node circuit does not use those two)."""
     c, inputs, expected = BuiltCircuit.random_program(seed, zero_knowledge=(seed == 101), num_inputs=10, num_ops=260, recursion_gates=True)
     w, p = c.witness(inputs, bytes(range(32)))
-    assert list(p) == list(expected) and c.desc.num_gates == 13
+    assert list(p) == list(expected) and c.desc.num_gates == 14
     oc, gc = OracleCircuit(c.desc), GpuCircuit(c.desc)
     from harness import keyed_salts
     salts = keyed_salts(TEST_SALT_KEY, 4, c.N) if c.desc.zero_knowledge else None

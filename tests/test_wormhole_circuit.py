@@ -334,14 +334,14 @@ def test_builder_fuzz_random_programs(seed):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_builder_fuzz_with_the_recursion_gates(seed):
-    """The same fuzz with the recursive verifier's gates mixed in (ArithmeticExtension, Reducing, ReducingExtension, RandomAccess, PoseidonMds,
-    CosetInterpolation, Exponentiation — layouts of SURVEY.md App. D as the oracle and the device evaluate them): every natively computed
+    """The same fuzz with the recursive verifier's gates mixed in (ArithmeticExtension, MulExtension, Reducing, ReducingExtension, RandomAccess,
+    PoseidonMds, CosetInterpolation, Exponentiation — all eight, layouts of SURVEY.md App. D as the oracle and the device evaluate them): every natively computed
     value is reproduced (Horner reductions over one to three rows, list look-ups, a native Lagrange interpolation, native powers), the
-    witness satisfies every gate and copy constraint of a gate list with four selector groups, and the oracle proves and verifies it."""
+    witness satisfies every gate and copy constraint of a gate list with five selector groups, and the oracle proves and verifies it."""
     c, inputs, expected = BuiltCircuit.random_program(100 + seed, zero_knowledge=(seed == 1), num_inputs=8 + seed, num_ops=150 + 40 * seed, recursion_gates=True)
-    assert c.desc.num_gates == 13 and c.desc.num_selector_groups == 4 and c.desc.num_constants == 6
+    assert c.desc.num_gates == 14 and c.desc.num_selector_groups == 5 and c.desc.num_constants == 7
     tags = [c.desc.gates[i].tag for i in range(c.desc.num_gates)]
-    assert tags == [9, 3, 12, 10, 2, 15, 14, 0, 1, 5, 13, 4, 11]                # by degree: Noop | Constant PublicInput PoseidonMds | BaseSum Reducing ReducingExt | Arithmetic ArithmeticExt | Exp | RandomAccess | Coset | Poseidon
+    assert tags == [9, 3, 12, 10, 2, 15, 14, 0, 1, 8, 5, 13, 4, 11]             # by degree: Noop | Constant PublicInput PoseidonMds | BaseSum Reducing ReducingExt | Arithmetic ArithmeticExt MulExt | Exp | RandomAccess | Coset | Poseidon
     w, p = c.witness(inputs, bytes(range(32)))
     assert list(p) == list(expected)
     oc = OracleCircuit(c.desc)

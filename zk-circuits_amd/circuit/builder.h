@@ -34,7 +34,7 @@ enum RowKind : uint8_t { K_NOOP = 0, K_CONST = 1, K_PI = 2, K_BASESUM = 3, K_ARI
                          K_EXP = 12, K_COSET = 13, K_ALL_KINDS = 14 };
 static const int W = 135, R = 80, BASESUM_LIMBS = 63, ARITH_OPS = 20, NSEL = 2, NC = 4;
 // parameters under standard_recursion_config (135 wires / 80 routed / D = 2)
-static const int ARITH_EXT_OPS = 10, REDUCING_COEFFS = 43, REDUCING_EXT_COEFFS = 32, RA_BITS = 4, RA_COPIES = 4, RA_EXTRA = 2, RA_VEC = 16,
+static const int ARITH_EXT_OPS = 10, MUL_EXT_OPS = 13, REDUCING_COEFFS = 43, REDUCING_EXT_COEFFS = 32, RA_BITS = 4, RA_COPIES = 4, RA_EXTRA = 2, RA_VEC = 16,
                  COSET_BITS = 4, COSET_NP = 16, COSET_DEG = 6, COSET_NI = (COSET_NP - 2) / (COSET_DEG - 1), EXP_BITS = 66;
 static const int COSET_S_POINT = 1 + 2 * COSET_NP, COSET_S_VALUE = COSET_S_POINT + 2, COSET_S_INTER = COSET_S_VALUE + 2, COSET_S_SHIFTED = COSET_S_INTER + 4 * COSET_NI;
 struct Ext2 { Target a, b; };                // an F_{p^2} value as two targets
@@ -222,6 +222,15 @@ class Builder {
     rec(Op{OP_ARITH_EXT, row_target(row, 0), 0, 0, 0, k0 % P, k1 % P, row, 0, 0, (uint32_t)s});
     return Ext2{row_target(row, 8 * s + 6), row_target(row, 8 * s + 7)};
   }
+  // MulExtension: out = k0 * m0 * m1 in F_{p^2} (13 per row; the verifier here uses ArithmeticExtension throughout, this one is for completeness)
+  Ext2 mul_ext(u64 k0, Ext2 m0, Ext2 m1) {
+    auto& open = open_mul_ext_[k0 % P];
+    if (open.second == 0) open.first = add_special_row(K_MUL_EXT, k0 % P, 0);
+    const uint32_t row = open.first; const int s = open.second; open.second = (s + 1) % MUL_EXT_OPS;
+    unite(row_target(row, 6 * s), m0.a); unite(row_target(row, 6 * s + 1), m0.b); unite(row_target(row, 6 * s + 2), m1.a); unite(row_target(row, 6 * s + 3), m1.b);
+    rec(Op{OP_MUL_EXT, row_target(row, 0), 0, 0, 0, k0 % P, 0, row, 0, 0, (uint32_t)s});
+    return Ext2{row_target(row, 6 * s + 4), row_target(row, 6 * s + 5)};
+  }
   // Reducing / ReducingExtension: Horner evaluation sum_i coeff_i * alpha^(count-1-i) (acc = acc * alpha + coeff, from zero), chained over
   // as many rows as the coefficients need; the first row is padded with leading zero coefficients (upstream's reduce_base / reduce).
   Ext2 reduce_base(Ext2 alpha, const std::vector<Target>& coeffs) {
@@ -299,7 +308,7 @@ class Builder {
 
  private:
   enum OpKind : uint8_t { OP_CONST, OP_ARITH, OP_INV, OP_SPLIT, OP_POSEIDON, OP_EXTINV, OP_LOHI,
-                          OP_ARITH_EXT, OP_REDUCING, OP_REDUCING_EXT, OP_RANDOM_ACCESS, OP_POSEIDON_MDS, OP_COSET, OP_EXP };   // whole-row / slot operations of the special gates
+                          OP_ARITH_EXT, OP_REDUCING, OP_REDUCING_EXT, OP_RANDOM_ACCESS, OP_POSEIDON_MDS, OP_COSET, OP_EXP, OP_MUL_EXT };   // whole-row / slot operations of the special gates
   struct Op { uint8_t kind; Target out, a, b, c; u64 k0, k1; uint32_t row; uint8_t stage = 0; uint32_t seg = 0; uint32_t slot = 0; };
   // Targets a special-gate operation reads and writes (row_target(row, col) = op.out + col), and its evaluation: `get(target)` returns a value,
   // `set(target, value)` stores one. One definition for witness generation (builder.cc) and the soundness sweep (mutation.cc).
@@ -365,6 +374,7 @@ class Builder {
   std::map<u64, Target> consts_; std::map<uint32_t, u64> const_val_;
   uint32_t const_row_ = 0; int const_slot_ = 0;
   std::map<std::pair<u64, u64>, std::pair<uint32_t, int>> open_arith_, open_arith_ext_;
+  std::map<u64, std::pair<uint32_t, int>> open_mul_ext_;
   uint32_t ra_row_ = 0; int ra_slot_ = 0;
   struct ArithKey { u64 k0, k1; uint32_t a, b, c; bool operator==(const ArithKey& o) const { return k0 == o.k0 && k1 == o.k1 && a == o.a && b == o.b && c == o.c; } };
   struct ArithHash { size_t operator()(const ArithKey& k) const { u64 h = k.k0 * 0x9E3779B97F4A7C15ULL ^ k.k1 * 0xC2B2AE3D27D4EB4FULL; h ^= ((u64)k.a << 32 | k.b) * 0x165667B19E3779F9ULL; h ^= (u64)k.c * 0x27D4EB2F165667C5ULL; return (size_t)(h ^ (h >> 29)); } };
@@ -389,6 +399,7 @@ template <class F> void Builder::special_reads(const Op& op, F&& f) {
   const Target t0 = op.out;
   switch (op.kind) {
     case OP_ARITH_EXT: for (int j = 0; j < 6; j++) f(t0 + 8 * op.slot + j); break;
+    case OP_MUL_EXT: for (int j = 0; j < 4; j++) f(t0 + 6 * op.slot + j); break;
     case OP_REDUCING: for (int j = 2; j < 6 + REDUCING_COEFFS; j++) f(t0 + j); break;
     case OP_REDUCING_EXT: for (int j = 2; j < 6 + 2 * REDUCING_EXT_COEFFS; j++) f(t0 + j); break;
     case OP_RANDOM_ACCESS: { const int base = (2 + RA_VEC) * (int)op.slot; f(t0 + base); for (int i = 0; i < RA_VEC; i++) f(t0 + base + 2 + i); break; }
@@ -402,6 +413,7 @@ template <class F> void Builder::special_writes(const Op& op, F&& f) {
   const Target t0 = op.out;
   switch (op.kind) {
     case OP_ARITH_EXT: f(t0 + 8 * op.slot + 6); f(t0 + 8 * op.slot + 7); break;
+    case OP_MUL_EXT: f(t0 + 6 * op.slot + 4); f(t0 + 6 * op.slot + 5); break;
     case OP_REDUCING: f(t0); f(t0 + 1); for (int j = 6 + REDUCING_COEFFS; j < 6 + REDUCING_COEFFS + 2 * (REDUCING_COEFFS - 1); j++) f(t0 + j); break;
     case OP_REDUCING_EXT: f(t0); f(t0 + 1); for (int j = 6 + 2 * REDUCING_EXT_COEFFS; j < 6 + 2 * REDUCING_EXT_COEFFS + 2 * (REDUCING_EXT_COEFFS - 1); j++) f(t0 + j); break;
     case OP_RANDOM_ACCESS: { const int routed = (2 + RA_VEC) * RA_COPIES + RA_EXTRA; f(t0 + (2 + RA_VEC) * (int)op.slot + 1); for (int i = 0; i < RA_BITS; i++) f(t0 + routed + RA_BITS * (int)op.slot + i); break; }
@@ -422,6 +434,7 @@ template <class G, class S> void Builder::special_eval(const Op& op, G&& get, S&
   auto sx = [&](int col, E v) { set(t0 + col, v.a); set(t0 + col + 1, v.b); };
   switch (op.kind) {
     case OP_ARITH_EXT: { const int b = 8 * (int)op.slot; sx(b + 6, add(scale(mul(gx(b), gx(b + 2)), op.k0), scale(gx(b + 4), op.k1))); break; }
+    case OP_MUL_EXT: { const int b = 6 * (int)op.slot; sx(b + 4, scale(mul(gx(b), gx(b + 2)), op.k0)); break; }
     case OP_REDUCING: case OP_REDUCING_EXT: {
       const bool xc = op.kind == OP_REDUCING_EXT; const int nc = xc ? REDUCING_EXT_COEFFS : REDUCING_COEFFS, start_accs = 6 + (xc ? 2 : 1) * nc;
       const E alpha = gx(2); E acc = gx(4);

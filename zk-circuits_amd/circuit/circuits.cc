@@ -356,7 +356,13 @@ extern "C" int qpc_test_random_circuit(uint64_t seed, uint32_t zero_knowledge, u
     const size_t i = pick(), j = pick(), k = pick();
     auto pick_ext = [&](Ext2& t2, E2& v2) { const size_t x = pick(), y = pick(); t2 = Ext2{t[x], t[y]}; v2 = E2{v[x], v[y]}; };
     if (recursion_gates && next() % 3 == 0) {
-      switch (next() % 7) {
+      switch (next() % 8) {
+        case 7: {                                                   // MulExtension
+          Ext2 m0, m1; E2 v0, v1; pick_ext(m0, v0); pick_ext(m1, v1);
+          const u64 k0 = next() % 3 == 0 ? next() % 2 : felt();
+          const Ext2 o = b.mul_ext(k0, m0, m1); const E2 ov = escale(emul(v0, v1), k0);
+          push(o.a, ov.a); push(o.b, ov.b); break;
+        }
         case 0: {                                                   // ArithmeticExtension
           Ext2 m0, m1, ad; E2 v0, v1, va; pick_ext(m0, v0); pick_ext(m1, v1); pick_ext(ad, va);
           const u64 k0 = next() % 3 == 0 ? next() % 2 : felt(), k1 = next() % 3 == 0 ? next() % 2 : felt();
